@@ -1,0 +1,91 @@
+"""Oracle for the fused random-policy rollout and for GAE (test infrastructure).
+
+``random_rollout`` restates, on top of ``OracleVectorEnv`` and the numpy Philox
+sampler, the loop the reference's random rollout runs
+("raw random-vs-random loop"):
+
+    a = RandomPolicy.act(obs)        # /root/reference/src/selfplay/policy.py:18-29
+    obs, r, d = env.step(a)          # src/env/torch_vector_mnk_env.py:55-84
+    env.reset(nonzero(d))            # src/env/torch_vector_mnk_env.py:34-44
+
+with the one substitution documented in ``philox.py``: the uniform legal move
+comes from Philox keyed by (seed, global env id, step) instead of
+``torch.multinomial``.  The HIP kernel ``mnk_rollout_random`` must reproduce the
+records and the final state of this function bit for bit.
+
+``gae`` restates ``RolloutBuffer.compute_advantages_and_returns``
+(``src/alg/rollout_buffer.py:60-80``) in f32 numpy, operation for operation.
+"""
+import numpy as np
+import torch
+
+from . import philox
+from .packing import pack_boards
+
+REC_ACTION_MASK = 0xFFFF
+REC_REWARD_SHIFT = 16  # i8 in bits 16..23
+REC_DONE_BIT = 24
+REC_SIDE_BIT = 25
+
+
+def encode_record(action, reward, done, side) -> np.ndarray:
+    a = np.asarray(action, dtype=np.int64) & REC_ACTION_MASK
+    r = (np.asarray(reward).astype(np.int64) & 0xFF) << REC_REWARD_SHIFT
+    d = np.asarray(done).astype(np.int64) << REC_DONE_BIT
+    s = np.asarray(side).astype(np.int64) << REC_SIDE_BIT
+    return (a | r | d | s).astype(np.uint32)
+
+
+def random_rollout(env, seed: int, step0: int, steps: int, env_id0: int = 0):
+    """Run ``steps`` random plies on every env of ``env`` (an OracleVectorEnv).
+
+    Returns (rec_planes u64[T,2,W,N], rec_meta u32[T,N], stats i64[5]) where the
+    planes are the absolute boards *before* the ply and stats =
+    [episodes finished, black wins, white wins, draws, sum of finished-episode lengths].
+    """
+    m, n = env.m, env.n
+    nenv = env.num_envs
+    ids = np.arange(env_id0, env_id0 + nenv, dtype=np.uint64)
+    rec_planes, rec_meta = [], []
+    stats = np.zeros(5, dtype=np.int64)
+    for t in range(steps):
+        before = env.observe()
+        side = env.current_player.numpy().copy()
+        rec_planes.append(pack_boards(before["observation"].numpy(), m, n))
+        x = philox.rand_u32(seed, ids, step0 + t, philox.STREAM_MOVE)
+        act = philox.pick_legal(before["action_mask"].numpy(), x)
+        _, rew, done = env.step(torch.from_numpy(act))
+        rew_np = rew.numpy()
+        done_np = done.numpy()
+        rec_meta.append(encode_record(act, rew_np.astype(np.int64), done_np, side))
+        if done_np.any():
+            lengths = env.move_counts.numpy()[done_np]
+            won = rew_np[done_np] == 1.0
+            stats[0] += int(done_np.sum())
+            stats[1] += int((won & (side[done_np] == 0)).sum())
+            stats[2] += int((won & (side[done_np] == 1)).sum())
+            stats[3] += int((~won).sum())
+            stats[4] += int(lengths.sum())
+            env.reset(torch.from_numpy(np.nonzero(done_np)[0]))
+    w = rec_planes[0].shape[1] if rec_planes else 0
+    planes = np.stack(rec_planes) if rec_planes else np.zeros((0, 2, w, nenv), np.uint64)
+    meta = np.stack(rec_meta) if rec_meta else np.zeros((0, nenv), np.uint32)
+    return planes, meta, stats
+
+
+def gae(rewards, values, dones, last_values, gamma=0.99, lam=0.95):
+    """f32 restatement of rollout_buffer.py:60-80.  Inputs are [T, N] (+ [N]); returns (adv, ret)."""
+    rewards = np.asarray(rewards, dtype=np.float32)
+    values = np.asarray(values, dtype=np.float32)
+    nonterm = np.float32(1.0) - np.asarray(dones).astype(np.float32)
+    steps = rewards.shape[0]
+    adv = np.zeros_like(rewards)
+    run = np.zeros(rewards.shape[1], dtype=np.float32)
+    g = np.float32(gamma)
+    gl = np.float32(gamma * lam)
+    for t in reversed(range(steps)):
+        nxt = np.asarray(last_values, dtype=np.float32).reshape(-1) if t == steps - 1 else values[t + 1]
+        delta = rewards[t] + g * nxt * nonterm[t] - values[t]
+        run = delta + gl * nonterm[t] * run
+        adv[t] = run
+    return adv, adv + values

@@ -1,0 +1,128 @@
+"""CPU: the oracle against the golden vectors made from the imported reference,
+and (when the reference tree is mounted) against the reference itself."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox
+from oracle.env_torch import OracleVectorEnv
+from oracle.packing import pack_boards, pack_cells, unpack_boards, unpack_cells, valid_cell_words, words_per_plane
+from oracle.pin_against_reference import ENV_CASES, SELFPLAY_CASES, check_env, check_selfplay, reference_available
+from oracle.policies import HighestLegalPolicy, LowestLegalPolicy, MaskHashPolicy
+from oracle.selfplay_torch import OracleSelfPlay
+from replay import golden_files, play_scenario, replay_env_log, replay_selfplay_trace
+from scenarios import SCENARIOS
+
+OPP = {"lowest": LowestLegalPolicy, "highest": HighestLegalPolicy, "hash": MaskHashPolicy}
+
+
+def test_golden_present(golden_dir):
+    assert len(golden_files(golden_dir, "env_")) >= 10
+    assert len(golden_files(golden_dir, "selfplay_")) >= 6
+
+
+@pytest.mark.parametrize("idx", range(11))
+def test_oracle_env_oplog(golden_dir, idx):
+    path = golden_files(golden_dir, "env_")[idx]
+    log = np.load(path)
+    m, n, k, nenv, _ = (int(v) for v in log["geom"])
+    replay_env_log(OracleVectorEnv(m, n, k, nenv), log)
+
+
+def _oracle_set_sides(wrapper, sides):
+    sides_t = torch.from_numpy(sides.astype(np.int64))
+
+    def source(count):
+        if count == wrapper.num_envs:  # reset(): one side per env
+            return sides_t.clone()
+        return sides_t[torch.nonzero(wrapper._resetting).squeeze(1)]
+
+    wrapper._side_source = source
+
+
+class _ReplayOracleSelfPlay(OracleSelfPlay):
+    def step(self, actions):
+        self._resetting = self.pending_resets.clone()
+        return super().step(actions)
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_oracle_selfplay_trace(golden_dir, idx):
+    path = golden_files(golden_dir, "selfplay_")[idx]
+    log = np.load(path)
+    m, n, k, nenv, _ = (int(v) for v in log["geom"])
+    opp = path.split("_")[-2]
+    wrap = _ReplayOracleSelfPlay(OracleVectorEnv(m, n, k, nenv))
+    wrap.set_opponent(OPP[opp]())
+    replay_selfplay_trace(wrap, log, _oracle_set_sides)
+
+
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+def test_oracle_edge_scenarios(golden_dir, name):
+    sc = SCENARIOS[name]
+    want = np.load(f"{golden_dir}/edges.npz")[name]
+    got = play_scenario(OracleVectorEnv(sc["m"], sc["n"], sc["k"], 1), sc)
+    assert np.array_equal(got, want)
+
+
+def test_reference_test_expectations():
+    """What the reference's own tests assert (src/tests/test_mnk_integration.py:50-65, 117-132)."""
+    want = SCENARIOS["row_win_3x3"]
+    rows = play_scenario(OracleVectorEnv(3, 3, 3, 1), want)
+    reward, done = rows[0][-4], rows[0][-3]
+    assert reward == 1 and done == 1
+
+
+def test_packing_roundtrip():
+    rng = np.random.default_rng(0)
+    for (m, n) in [(3, 3), (4, 6), (9, 9), (13, 13), (19, 19), (7, 9)]:
+        b = (rng.random((17, 2, m, n)) < 0.4).astype(np.float32)
+        p = pack_boards(b, m, n)
+        assert p.shape == (2, words_per_plane(m, n), 17) and p.dtype == np.uint64
+        assert np.array_equal(unpack_boards(p, m, n), b)
+        # guard column and padding bits stay clear
+        assert not np.any(p & ~valid_cell_words(m, n)[None, :, None])
+        cells = rng.random((5, m * n)) < 0.5
+        assert np.array_equal(unpack_cells(pack_cells(cells, m, n), m, n), cells.astype(np.uint8))
+    assert [words_per_plane(*s) for s in [(3, 3), (9, 9), (13, 13), (19, 19)]] == [1, 2, 3, 6]
+
+
+def test_philox_known_answers():
+    """Random123 known-answer vectors for philox4x32-10 (kat_vectors of the Random123 distribution)."""
+    kat = [
+        ((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+        ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2, (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+        ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+         (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)),
+    ]
+    for ctr, key, want in kat:
+        got = philox.philox4x32_10(*ctr, *key)
+        assert tuple(int(v) for v in got) == want
+
+
+def test_pick_legal_is_uniform_and_legal():
+    rng = np.random.default_rng(1)
+    mask = rng.random((4000, 9)) < 0.6
+    mask[0] = False
+    x = philox.rand_u32(7, np.arange(4000), 0, philox.STREAM_MOVE)
+    a = philox.pick_legal(mask, x)
+    rows = np.nonzero(mask.any(axis=1))[0]
+    assert mask[rows, a[rows]].all()
+    assert 0 <= a[0] < 9
+    one = np.zeros((60000, 9), dtype=bool)
+    one[:, [1, 4, 7]] = True
+    a = philox.pick_legal(one, philox.rand_u32(3, np.arange(60000), 5, philox.STREAM_MOVE))
+    counts = np.bincount(a, minlength=9)[[1, 4, 7]]
+    assert counts.sum() == 60000 and np.all(np.abs(counts - 20000) < 600)
+
+
+@pytest.mark.skipif(not reference_available(), reason="reference tree not mounted (GPU box)")
+@pytest.mark.parametrize("case", ENV_CASES[:5])
+def test_oracle_env_equals_reference(case):
+    assert check_env(*case)
+
+
+@pytest.mark.skipif(not reference_available(), reason="reference tree not mounted (GPU box)")
+@pytest.mark.parametrize("case", SELFPLAY_CASES[:6])
+def test_oracle_selfplay_equals_reference(case):
+    assert check_selfplay(*case)
