@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""bench.py -- random-policy rollout throughput of the MNK self-play path on MI355X.
+
+Metric (BASELINE.json): env-steps/sec, 9x9x5, 65 536 parallel envs per GPU, random-policy
+rollout.  A "step" is one ply on every env of the batch: uniform legal move (RandomPolicy),
+place stone, 4-direction win scan, reward/done, restart of finished games, packed record
+written to HBM -- executed by the fused kernel ``mnk_rollout_random`` in chunks of
+``--chunk`` plies per launch.  With --gpus N > 1 the env axis is sharded (65 536 envs per
+rank, global env ids key the RNG) and every chunk's packed records are all-gathered over
+RCCL on a side stream while the next chunk runs.
+
+    python bench.py                       # 1 GPU, defaults finish in well under a minute
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8
+
+Rank 0 prints ONE JSON line (driver contract) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "rl-selfplay-mnk_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4096)
+    ap.add_argument("--warmup", type=int, default=256)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--board", type=str, default="9x9x5")
+    ap.add_argument("--chunk", type=int, default=64, help="plies per launch of the fused rollout kernel")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-api-path", action="store_true", help="skip the extra per-step-launch measurement")
+    return ap.parse_args()
+
+
+def record_bytes(words):
+    """Algorithmic HBM bytes of one env-step inside the fused rollout:
+    the packed record R = 16*W + 4 that is written for every ply; the state itself lives in
+    registers for the whole launch (its load/store is amortised over the chunk)."""
+    return 16 * words + 4
+
+
+def state_bytes(words):
+    return 16 * words + 4
+
+
+def cpu_baseline(env, seconds):
+    """The oracle's torch-eager restatement of the reference env (conv2d win scan) and of
+    RandomPolicy (multinomial), timed on the host cores from the GPU env's current (stationary)
+    position.  Test infrastructure used as the reported CPU baseline -- never the product path."""
+    from oracle.env_torch import OracleVectorEnv
+    from oracle.policies import OracleRandomPolicy
+
+    n = env.num_envs
+    ora = OracleVectorEnv(env.m, env.n, env.k, n)
+    ora.boards.copy_(env.boards.cpu())
+    ora.current_player.copy_(env.current_player.cpu())
+    ora.move_counts.copy_(env.move_counts.cpu())
+    pol = OracleRandomPolicy(env.m * env.n)
+    torch.manual_seed(0)
+    obs = ora.observe()
+
+    def one(obs):
+        a = pol.act(obs)
+        obs, _, d = ora.step(a)
+        if bool(d.any()):
+            ora.reset(torch.nonzero(d).squeeze(1))
+            obs = ora.observe()
+        return obs
+
+    for _ in range(2):
+        obs = one(obs)
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        obs = one(obs)
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {
+        "value": steps * n / dt,
+        "unit": "env-steps/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{steps} plies x {n} envs ({env.m}x{env.n}x{env.k}) from the GPU env's stationary position, "
+                  f"{dt:.1f} s; oracle/env_torch.py (torch eager, conv2d win scan) + multinomial RandomPolicy",
+    }
+
+
+def api_path_rate(env, seed, steps=200):
+    """The same workload through the API-level kernels, one launch each per ply:
+    mnk_sample_legal -> mnk_step (rewards, dones, legal mask) -> mnk_reset_mask(done).
+    Launch-latency bound at this batch size; reported for transparency only."""
+    n, dev = env.num_envs, env._dev
+    acts = torch.empty(n, dtype=torch.long, device=dev)
+    rew = torch.empty(n, dtype=torch.float32, device=dev)
+    done = torch.empty(n, dtype=torch.bool, device=dev)
+    mask = torch.empty((n, env.max_moves), dtype=torch.bool, device=dev)
+
+    def ply(t):
+        env.sample_legal_into(acts, seed=seed, step=t)
+        env.step_into(acts, rew, done, mask)
+        env.reset_mask_(done)
+
+    for t in range(20):
+        ply(t)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for t in range(steps):
+        ply(1000 + t)
+    torch.cuda.synchronize(dev)
+    return steps * n / (time.perf_counter() - t0)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        args.gpus = world
+
+    import mnk_hip
+    from env.torch_vector_mnk_env import TorchVectorMnkEnv
+    from selfplay.random_rollout import RandomRollout
+
+    mnk_hip.load()
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    m, n, k = (int(v) for v in args.board.split("x"))
+    nenv, chunk = args.envs, args.chunk
+    env = TorchVectorMnkEnv(m, n, k, nenv, device=str(dev))
+    env.reset()
+    roll = RandomRollout(env, seed=args.seed, env_id0=rank * nenv)
+    bufs = [roll.alloc(chunk) for _ in range(2)]
+    gathered = side = None
+    if world > 1:
+        side = torch.cuda.Stream(dev)
+        gathered = [(torch.empty((world,) + tuple(b.planes.shape), dtype=torch.int64, device=dev),
+                     torch.empty((world,) + tuple(b.meta.shape), dtype=torch.int32, device=dev)) for b in bufs]
+    main_stream = torch.cuda.current_stream(dev)
+    gather_done = [None, None]
+
+    def run_steps(total):
+        """`total` plies per env: ceil(total/chunk) launches; the records of each chunk are all-gathered
+        on the side stream while the next chunk computes.  Returns the number of launches."""
+        launches, done, c = 0, 0, 0
+        while done < total:
+            t = min(chunk, total - done)
+            slot = c & 1
+            if gather_done[slot] is not None:
+                main_stream.wait_event(gather_done[slot])  # the buffer is free again
+            out = bufs[slot]
+            if t != chunk:
+                out = type(out)(planes=out.planes[:t], meta=out.meta[:t])
+            roll.run(t, out=out)
+            launches += 1
+            if world > 1:
+                ready = torch.cuda.Event()
+                ready.record(main_stream)
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    if t == chunk:
+                        gp, gm = gathered[slot]
+                    else:  # ragged last chunk: its own (contiguous) landing buffers
+                        gp = torch.empty((world,) + tuple(out.planes.shape), dtype=torch.int64, device=dev)
+                        gm = torch.empty((world,) + tuple(out.meta.shape), dtype=torch.int32, device=dev)
+                    dist.all_gather_into_tensor(gp, out.planes)
+                    dist.all_gather_into_tensor(gm, out.meta)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    gather_done[slot] = ev
+            done += t
+            c += 1
+        if world > 1:
+            main_stream.wait_stream(side)
+        return launches
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    run_steps(args.warmup)
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(main_stream)
+    launches = run_steps(args.steps)
+    e1.record(main_stream)
+    barrier()
+    dt = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    value = world * nenv * args.steps / dt
+    words = env.words
+    # roofline of the dominant kernel (mnk_rollout_random): algorithmic bytes per launch / avg launch time
+    plies_per_launch = args.steps / launches
+    alg_bytes = nenv * (plies_per_launch * record_bytes(words) + 2 * state_bytes(words))
+    launch_s = dev_ms * 1e-3 / launches
+    achieved = alg_bytes / launch_s / 1e9
+    survey_b_roll = state_bytes(words) + 8 * words + 4 + record_bytes(words)  # 92 B at 9x9
+    out = {
+        "metric": f"env-steps/sec {m}x{n}x{k}, {nenv} parallel envs/GPU, random-policy rollout",
+        "value": value,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt * 1e3 / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{m}x{n}x{k}, {nenv} envs/GPU, fused random rollout (sample+step+win-scan+reset+record), "
+                        f"{chunk} plies/launch" + (f", records all-gathered over RCCL across {world} GPUs" if world > 1 else ""),
+            "envs_per_gpu": nenv, "chunk": chunk, "board": args.board, "seed": args.seed,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": "k_rollout_random",
+            "launches": launches,
+            "avg_launch_us": launch_s * 1e6,
+            "alg_bytes_per_env_step": record_bytes(words) + 2 * state_bytes(words) / plies_per_launch,
+            "achieved_at_survey_B_roll": survey_b_roll * nenv * plies_per_launch / launch_s / 1e9,
+        },
+    }
+    if rank == 0:
+        stats = roll.stats.tolist()
+        out["rollout_stats"] = {"episodes": stats[0], "mean_plies": stats[4] / max(stats[0], 1),
+                                "draw_rate": stats[3] / max(stats[0], 1)}
+        if world == 1 and not args.no_api_path:
+            out["api_path_env_steps_per_s"] = api_path_rate(env, args.seed)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(env, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

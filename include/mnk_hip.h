@@ -1,0 +1,179 @@
+/*
+ * mnk_hip.h -- C ABI of libmnk_hip.so, the MI355X (gfx950) implementation of the
+ * vectorized MNK self-play rollout path.
+ *
+ * The reference (michal-szadkowski/rl-selfplay-mnk) has no FFI layer: its boundary
+ * is the duck-typed Python surface of TorchVectorMnkEnv / TorchSelfPlayWrapper.
+ * The Python classes in rl-selfplay-mnk_amd/{env,selfplay}/ keep that surface and
+ * call the functions below through ctypes; every entry point cites the reference
+ * code it replaces (paths relative to the reference's src/).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name says host; buffers are owned
+ *     by the caller (torch tensors on the Python side) and must be contiguous;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     every function only enqueues work on it: no allocation, no synchronisation,
+ *     no host<->device copy, so all of them may be captured into a hipGraph;
+ *   - return value: MNK_OK (0) or a negative MNK_E* code for an argument error that
+ *     was detected on the host (nothing is enqueued then);
+ *   - data-dependent errors (action out of range, illegal move in strict mode) are
+ *     recorded on the device in `err` = int32[2] {code, global env id}; first error
+ *     wins, the word is sticky until the caller clears it.  The offending env is
+ *     left untouched, all other envs proceed;
+ *   - single writer per state buffer: calls that touch the same state must be
+ *     ordered on one stream (or by events).  No global mutable state in the library.
+ *
+ * Packed state:
+ *   planes  u64[2][W][N]   plane 0 = black, 1 = white; cell (r,c) is bit r*(n+1)+c of the
+ *                          W-word little-endian bit string; column n of each row is a
+ *                          guard column that is always 0;  W = mnk_state_words(m, n)
+ *   meta    u32[N]         bit 0 = side to move (0 black, 1 white), bits 1..31 = move count
+ */
+#ifndef MNK_HIP_H
+#define MNK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MNK_ABI_VERSION 1
+
+/* status codes (host-side argument checks) */
+#define MNK_OK 0
+#define MNK_EINVAL -1   /* null pointer / negative size */
+#define MNK_EGEOM -2    /* unsupported board geometry (see mnk_geometry_supported) */
+#define MNK_ELAUNCH -3  /* hipLaunchKernel failed (hipGetLastError text via mnk_last_launch_error) */
+
+/* device-side error codes written to err[0] */
+#define MNK_ERR_NONE 0
+#define MNK_ERR_ACTION_RANGE 1 /* action outside [-m*n, m*n): the reference raises IndexError (env/torch_vector_mnk_env.py:68) */
+#define MNK_ERR_ILLEGAL_MOVE 2 /* strict mode only: occupied cell, message of env/torch_vector_mnk_env.py:102-104 */
+
+/* flags for mnk_step */
+#define MNK_STEP_STRICT 1u /* refuse moves onto occupied cells (the behaviour tests/test_mnk_integration.py:68-81 expects) */
+
+/* flags written by mnk_selfplay_pre for mnk_selfplay_post (u8 per env) */
+#define MNK_SP_NEED_OPP 1u
+#define MNK_SP_WAS_RESET 2u
+
+/* rollout record meta word (u32 per env-step) */
+#define MNK_REC_ACTION_MASK 0xFFFFu
+#define MNK_REC_REWARD_SHIFT 16 /* i8 */
+#define MNK_REC_DONE_BIT 24
+#define MNK_REC_SIDE_BIT 25
+
+/* Philox streams (oracle/philox.py restates the generator) */
+#define MNK_STREAM_MOVE 0
+#define MNK_STREAM_OPP 1
+#define MNK_STREAM_SIDE 2
+#define MNK_STREAM_GUMBEL 3
+
+int mnk_abi_version(void);
+/* W = ceil(m*(n+1)/64), or 0 when the geometry is unsupported */
+int mnk_state_words(int m, int n);
+/* 1 when 1 <= k <= min(m,n), n <= 61 and W <= 8 (boards up to 22x22) */
+int mnk_geometry_supported(int m, int n, int k);
+const char* mnk_last_launch_error(void);
+
+/* ---- env/torch_vector_mnk_env.py:34-44  reset(env_indices=None) ------------------- */
+int mnk_reset_all(uint64_t* planes, uint32_t* meta, int64_t N, int W, void* stream);
+/* idx: R int64 env indices (negative indices wrap like torch indexing); out-of-range -> err */
+int mnk_reset_idx(uint64_t* planes, uint32_t* meta, int64_t N, int W, const int64_t* idx, int64_t R,
+                  int32_t* err, void* stream);
+/* mask: u8[N], non-zero = reset (fixed-shape form used by the fused paths) */
+int mnk_reset_mask(uint64_t* planes, uint32_t* meta, int64_t N, int W, const uint8_t* mask, void* stream);
+
+/* ---- env/torch_vector_mnk_env.py:55-84 + 106-119  step / step_subset / _check_wins ---
+ * actions: int64[A]; active_idx: int64[A] ascending unique env ids, or NULL for the full
+ * batch (then A must equal N).  rewards f32[N] / dones u8[N] are FULL-SIZE as in the
+ * reference (:75-80): zero outside the active set.  legal_mask u8[N][m*n] and
+ * obs f32[N][2][m][n] (absolute planes, env/torch_vector_mnk_env.py:46-53) are optional
+ * (NULL = skip) and always cover all N envs. */
+int mnk_step(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k,
+             const int64_t* actions, const int64_t* active_idx, int64_t A,
+             float* rewards, uint8_t* dones, uint8_t* legal_mask, float* obs,
+             int32_t* err, uint32_t flags, void* stream);
+
+/* ---- env/torch_vector_mnk_env.py:46-53 observe() and
+ *      selfplay/torch_self_play_wrapper.py:99-112 _get_canonical_obs() --------------------
+ * flip_side: NULL -> absolute planes; else int64[N], envs with flip_side==1 get the two
+ * planes swapped (the agent sees itself in channel 0).  fix_empty_mask != 0 sets
+ * mask[i][0] = 1 for rows without a legal cell (wrapper:108-110). obs or mask may be NULL. */
+int mnk_observe(const uint64_t* planes, const uint32_t* meta, int64_t N, int m, int n,
+                const int64_t* flip_side, float* obs, uint8_t* legal_mask, int fix_empty_mask,
+                void* stream);
+
+/* dense (N,2,m,n) f32 <-> packed planes: backs the writable `env.boards` view
+ * (tests/test_mnk_integration.py:57-58 pokes stones in).  A cell is a stone when != 0. */
+int mnk_pack_boards(const float* boards, uint64_t* planes, int64_t N, int m, int n, void* stream);
+int mnk_unpack_boards(const uint64_t* planes, float* boards, int64_t N, int m, int n, void* stream);
+
+/* ---- selfplay/policy.py:13-29 RandomPolicy.act -------------------------------------------
+ * One uniformly drawn legal cell per env, from Philox(seed, env_id0 + i, step, stream_id).
+ * Rows without a legal cell draw uniformly over all cells (the 1e-8 guard of policy.py:21-24). */
+int mnk_sample_legal(const uint64_t* planes, int64_t N, int m, int n, uint64_t seed, uint64_t step,
+                     int64_t env_id0, int stream_id, int64_t* actions, void* stream);
+
+/* ---- alg/architectures/cnn.py:69-79 (= resnet.py:84-95, transformer.py:80-91) + policy.py:46-52
+ * Masked categorical head fused with the draw: logits f32[N][C] (any additive normalisation),
+ * mask u8[N][C].  deterministic != 0 -> argmax over legal cells (policy.py:48-49); else a
+ * Gumbel-max draw from softmax(masked logits).  All-masked row -> uniform over C (cnn.py:76-77).
+ * logp (optional) = log-probability of the chosen action under the masked softmax. */
+int mnk_sample_logits(const float* logits, const uint8_t* mask, int64_t N, int C, uint64_t seed,
+                      uint64_t step, int64_t env_id0, int deterministic, int64_t* actions, float* logp,
+                      void* stream);
+
+/* ---- selfplay/torch_self_play_wrapper.py:32-67 step(), split around the opponent forward ----
+ * pre : envs with pending != 0 are reset instead of stepped (their action is ignored), get a
+ *       fresh side (forced_side[i] if given, else the top bit of Philox(seed, env, step, SIDE));
+ *       the others play the agent's ply.  Writes partial rewards / terminated, the per-env
+ *       flags for `post`, and the opponent's view (itself in channel 0, wrapper:83-89) for
+ *       every env; rows that need no reply carry their current position and are ignored later.
+ * post: envs flagged NEED_OPP play opp_actions; zero-sum merge (wrapper:59-63: reward -= r_opp,
+ *       terminated = done_opp, both skipped for freshly reset envs :46); pending = terminated;
+ *       writes the agent's canonical observation and mask (wrapper:99-112). */
+int mnk_selfplay_pre(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k,
+                     const int64_t* actions, const uint8_t* pending, int64_t* agent_side,
+                     const int64_t* forced_side, uint64_t seed, uint64_t step, int64_t env_id0,
+                     float* rewards, uint8_t* terminated, uint8_t* sp_flags,
+                     float* opp_obs, uint8_t* opp_mask, int32_t* err, void* stream);
+int mnk_selfplay_post(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k,
+                      const int64_t* opp_actions, const uint8_t* sp_flags, const int64_t* agent_side,
+                      float* rewards, uint8_t* terminated, uint8_t* pending,
+                      float* obs, uint8_t* legal_mask, int32_t* err, void* stream);
+/* Whole wrapper.step in ONE launch for a uniformly random opponent (RandomPolicy, policy.py:13-29):
+ * pre + Philox legal draw (stream OPP) + post. */
+int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k,
+                             const int64_t* actions, uint8_t* pending, int64_t* agent_side,
+                             const int64_t* forced_side, uint64_t seed, uint64_t step, int64_t env_id0,
+                             float* rewards, uint8_t* terminated, float* obs, uint8_t* legal_mask,
+                             int32_t* err, void* stream);
+
+/* ---- the random-policy rollout of BASELINE.json (RandomPolicy.act -> env.step -> env.reset(done)),
+ * T plies per env in one launch with the state held in registers.
+ * rec_planes u64[T][2][W][N]: absolute planes BEFORE each ply; rec_meta u32[T][N]: MNK_REC_* word;
+ * stats (optional) int64[5] += {episodes finished, black wins, white wins, draws, sum of episode lengths}.
+ * rec_planes / rec_meta may be NULL (state-only rollout). */
+int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, int T,
+                       uint64_t seed, uint64_t step0, int64_t env_id0,
+                       uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats, void* stream);
+
+/* Unpack gathered records into the reference's RolloutBuffer layout (alg/rollout_buffer.py:14-44):
+ * obs f32[T][N][2][m][n] from the mover's point of view, masks u8[T][N][C], actions i64[T][N],
+ * rewards f32[T][N], dones u8[T][N].  Any output may be NULL. */
+int mnk_unpack_records(const uint64_t* rec_planes, const uint32_t* rec_meta, int64_t N, int T, int m, int n,
+                       float* obs, uint8_t* masks, int64_t* actions, float* rewards, uint8_t* dones,
+                       void* stream);
+
+/* ---- alg/rollout_buffer.py:60-80 compute_advantages_and_returns (GAE), one lane per env ---- */
+int mnk_gae(const float* rewards, const float* values, const uint8_t* dones, const float* last_values,
+            int64_t N, int T, float gamma, float gamma_lambda, float* advantages, float* returns,
+            void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MNK_HIP_H */

@@ -81,3 +81,22 @@ class FixedCellPolicy:
     def act(self, obs):
         mask = obs["action_mask"]
         return torch.full((mask.shape[0],), self.cell, dtype=torch.int64, device=mask.device)
+
+
+class PhiloxOpponent:
+    """Uniform legal reply keyed by (seed, global env id, step): what the fused HIP step
+    ``mnk_selfplay_step_random`` draws for its built-in random opponent (stream OPP).
+    ``OracleSelfPlay`` hands the env indices of the rows through ``act_indexed``; the test sets
+    ``step`` before every wrapper call."""
+
+    def __init__(self, seed: int, env_id0: int = 0):
+        self.seed, self.env_id0, self.step = int(seed), int(env_id0), 0
+
+    def act_indexed(self, obs, idx):
+        import numpy as np
+
+        from . import philox
+
+        ids = (idx.numpy() + self.env_id0).astype(np.uint64)
+        x = philox.rand_u32(self.seed, ids, self.step, philox.STREAM_OPP)
+        return torch.from_numpy(philox.pick_legal(obs["action_mask"].numpy(), x))

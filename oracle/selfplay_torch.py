@@ -90,7 +90,11 @@ class OracleSelfPlay:
         if bool(as_white.any()):
             obs[as_white] = torch.flip(obs[as_white], dims=(1,))
         with torch.no_grad():
-            acts = self.opponent_policy.act({"observation": obs, "action_mask": mask})
+            view = {"observation": obs, "action_mask": mask}
+            if hasattr(self.opponent_policy, "act_indexed"):  # oracle-only hook: policies keyed by env id
+                acts = self.opponent_policy.act_indexed(view, idx)
+            else:
+                acts = self.opponent_policy.act(view)
         self.last_opponent_actions = (idx.clone(), acts.clone())
         _, r, d = self.env.step_subset(acts, idx)
         return r, d

@@ -1,0 +1,827 @@
+// mnk_kernels.hip -- HIP kernels + C ABI of libmnk_hip.so (gfx950 / MI355X only).
+//
+// Replaces, behind include/mnk_hip.h, the ATen op sequences of the reference's
+// env/torch_vector_mnk_env.py and selfplay/torch_self_play_wrapper.py (SURVEY.md
+// section 2.1).  All of this is integer bit manipulation bounded by HBM traffic:
+// no MFMA, no library calls.  Mapping: one lane per env for the game logic
+// (coalesced 8-byte accesses over the env axis of the SoA state), one workgroup per
+// B consecutive envs, and the same env -> workgroup map in every kernel so an env's
+// state stays in the L2 of the XCD that touched it last.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mnk_hip.h"
+#include "mnk_device.h"
+#include "mnk_emit.h"
+
+// ------------------------------------------------------------------ host helpers
+static thread_local char g_launch_err[256] = "";
+
+static int mnk_make_geom(int m, int n, int k, MnkGeom* g) {
+  if (m < 1 || n < 1 || k < 1 || k > m || k > n || n > 61) return MNK_EGEOM;
+  const int bits = m * (n + 1);
+  const int W = (bits + 63) / 64;
+  if (W > MNK_MAX_W) return MNK_EGEOM;
+  memset(g, 0, sizeof(*g));
+  g->m = m; g->n = n; g->k = k;
+  g->C = m * n; g->W = W; g->stride = n + 1;
+  auto magic = [](uint32_t d) { return (uint32_t)((1ull << 32) / d + 1ull); };
+  g->magic_n = n == 1 ? 0u : magic((uint32_t)n);  // n == 1: x / 1 handled below
+  g->magic_stride = magic((uint32_t)(n + 1));
+  g->magic_C = g->C == 1 ? 0u : magic((uint32_t)g->C);
+  g->magic_2C = magic((uint32_t)(2 * g->C));
+  for (int r = 0; r < m; ++r)
+    for (int c = 0; c < n; ++c) {
+      const int b = r * (n + 1) + c;
+      g->valid[b >> 6] |= 1ull << (b & 63);
+    }
+  return MNK_OK;
+}
+
+// division by 1 cannot use the 32-bit magic (2^32 + 1 overflows); boards with n == 1 or a
+// single cell are degenerate and rejected instead of carrying a special case in every kernel
+static int mnk_check_geom(int m, int n, int k, MnkGeom* g) {
+  int rc = mnk_make_geom(m, n, k, g);
+  if (rc != MNK_OK) return rc;
+  if (n < 2) return MNK_EGEOM;
+  return MNK_OK;
+}
+
+static int mnk_launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return MNK_OK;
+  snprintf(g_launch_err, sizeof(g_launch_err), "%s: %s", what, hipGetErrorString(e));
+  return MNK_ELAUNCH;
+}
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// workgroup size for kernels with a write-out stage (envs per workgroup)
+static int mnk_block_envs(int64_t N) {
+  (void)N;
+  return 64;
+}
+
+#define MNK_DISPATCH_W(W, CALL)                      \
+  do {                                               \
+    switch (W) {                                     \
+      case 1: { constexpr int WT = 1; CALL; } break; \
+      case 2: { constexpr int WT = 2; CALL; } break; \
+      case 3: { constexpr int WT = 3; CALL; } break; \
+      case 4: { constexpr int WT = 4; CALL; } break; \
+      case 5:                                        \
+      case 6: { constexpr int WT = 6; CALL; } break; \
+      default: { constexpr int WT = 8; CALL; } break; \
+    }                                                \
+  } while (0)
+
+// ------------------------------------------------------------------ reset
+__global__ void k_reset_idx(uint64_t* planes, uint32_t* meta, int64_t N, int W, const int64_t* idx, int64_t R,
+                            int32_t* err) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= R) return;
+  int64_t i = idx[j];
+  if (i < 0) i += N;
+  if (i < 0 || i >= N) { mnk_report(err, MNK_ERR_ACTION_RANGE, idx[j]); return; }
+  for (int w = 0; w < 2 * W; ++w) planes[(int64_t)w * N + i] = 0ull;
+  meta[i] = 0u;
+}
+
+__global__ void k_reset_mask(uint64_t* planes, uint32_t* meta, int64_t N, int W, const uint8_t* mask) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N || !mask[i]) return;
+  for (int w = 0; w < 2 * W; ++w) planes[(int64_t)w * N + i] = 0ull;
+  meta[i] = 0u;
+}
+
+// ------------------------------------------------------------------ step (full batch, fused write-out)
+template <int WT>
+__global__ void __launch_bounds__(256)
+k_step_full(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions, float* rewards,
+            uint8_t* dones, uint8_t* legal_mask, float* obs, int32_t* err, uint32_t flags, int vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int B = blockDim.x, tid = threadIdx.x;
+  const int64_t env0 = (int64_t)blockIdx.x * B;
+  const int64_t i = env0 + tid;
+  const bool emit = (legal_mask != nullptr) || (obs != nullptr);
+  MnkStage st = mnk_stage_carve(lds_raw, g, B);
+  if (emit) mnk_stage_tables(st, g, B, tid, B);
+  if (i < N) {
+    MnkEnv<WT> e;
+    env_load<WT>(e, planes, meta, N, g.W, i);
+    MnkPly ply = env_play<WT>(g, e, actions[i], (flags & MNK_STEP_STRICT) != 0);
+    if (ply.err) mnk_report(err, ply.err, i);
+    else env_store<WT>(e, planes, meta, N, g.W, i);
+    rewards[i] = ply.win ? 1.0f : 0.0f;   // :75-77
+    dones[i] = ply.done ? 1 : 0;          // :79-80
+    if (emit) mnk_stage_put<WT>(st, g, B, tid, e.p[0], e.p[1], false);
+  }
+  if (emit) {
+    __syncthreads();
+    const int64_t left = N - env0;
+    const int nb = left < B ? (int)left : B;
+    if (obs) mnk_emit_obs(st, g, nb, obs + env0 * 2 * g.C, vec_ok & 1, tid, B);
+    if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, B);
+  }
+}
+
+// step_subset: lane j plays env active_idx[j]; rewards / dones were zero-filled by the launcher
+template <int WT>
+__global__ void __launch_bounds__(256)
+k_step_subset(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions,
+              const int64_t* active_idx, int64_t A, float* rewards, uint8_t* dones, int32_t* err,
+              uint32_t flags) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= A) return;
+  int64_t i = active_idx[j];
+  if (i < 0) i += N;
+  if (i < 0 || i >= N) { mnk_report(err, MNK_ERR_ACTION_RANGE, active_idx[j]); return; }
+  MnkEnv<WT> e;
+  env_load<WT>(e, planes, meta, N, g.W, i);
+  MnkPly ply = env_play<WT>(g, e, actions[j], (flags & MNK_STEP_STRICT) != 0);
+  if (ply.err) { mnk_report(err, ply.err, i); return; }
+  env_store<WT>(e, planes, meta, N, g.W, i);
+  rewards[i] = ply.win ? 1.0f : 0.0f;
+  dones[i] = ply.done ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ observe / unpack
+template <int WT>
+__global__ void __launch_bounds__(256)
+k_observe(MnkGeom g, const uint64_t* planes, int64_t N, const int64_t* flip_side, float* obs,
+          uint8_t* legal_mask, int fix_empty, int vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int B = blockDim.x, tid = threadIdx.x;
+  const int64_t env0 = (int64_t)blockIdx.x * B;
+  const int64_t i = env0 + tid;
+  MnkStage st = mnk_stage_carve(lds_raw, g, B);
+  mnk_stage_tables(st, g, B, tid, B);
+  if (i < N) {
+    uint64_t a[WT], b[WT];
+    const bool flip = flip_side && flip_side[i] == 1;  // wrapper:104-106
+#pragma unroll
+    for (int w = 0; w < WT; ++w) {
+      const uint64_t p0 = w < g.W ? planes[(int64_t)(0 * g.W + w) * N + i] : 0ull;
+      const uint64_t p1 = w < g.W ? planes[(int64_t)(1 * g.W + w) * N + i] : 0ull;
+      a[w] = flip ? p1 : p0;
+      b[w] = flip ? p0 : p1;
+    }
+    mnk_stage_put<WT>(st, g, B, tid, a, b, fix_empty != 0);
+  }
+  __syncthreads();
+  const int64_t left = N - env0;
+  const int nb = left < B ? (int)left : B;
+  if (obs) mnk_emit_obs(st, g, nb, obs + env0 * 2 * g.C, vec_ok & 1, tid, B);
+  if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, B);
+}
+
+// dense f32 -> packed; rare path (the writable env.boards view), one lane per env
+__global__ void k_pack_boards(MnkGeom g, const float* boards, uint64_t* planes, int64_t N) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  for (int pl = 0; pl < 2; ++pl) {
+    const float* src = boards + (i * 2 + pl) * g.C;
+    uint64_t word = 0;
+    int cur = 0;
+    for (int r = 0; r < g.m; ++r)
+      for (int c = 0; c < g.n; ++c) {
+        const int bit = r * g.stride + c;
+        if ((bit >> 6) != cur) {
+          planes[(int64_t)(pl * g.W + cur) * N + i] = word;
+          word = 0;
+          cur = bit >> 6;
+        }
+        if (src[r * g.n + c] != 0.0f) word |= 1ull << (bit & 63);
+      }
+    planes[(int64_t)(pl * g.W + cur) * N + i] = word;
+    for (int w = cur + 1; w < g.W; ++w) planes[(int64_t)(pl * g.W + w) * N + i] = 0ull;
+  }
+}
+
+// ------------------------------------------------------------------ RandomPolicy
+template <int WT>
+__global__ void __launch_bounds__(256)
+k_sample_legal(MnkGeom g, const uint64_t* planes, int64_t N, uint64_t seed, uint64_t step, int64_t env_id0,
+               uint32_t stream_id, int64_t* actions) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  MnkEnv<WT> e;
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+    for (int w = 0; w < WT; ++w) e.p[pl][w] = (w < g.W) ? planes[(int64_t)(pl * g.W + w) * N + i] : 0ull;
+  const uint32_t x = mnk_rand_u32(seed, (uint64_t)(env_id0 + i), step, stream_id);
+  actions[i] = env_pick_legal<WT>(g, e, x);
+}
+
+// ------------------------------------------------------------------ fused random rollout
+// T plies per env in one launch; state lives in registers, HBM sees one load and one
+// store of the state per launch plus the 36-byte (9x9) record of every ply.
+// Wave-level bookkeeping: finished games are counted with ballot + popcount (one scalar
+// add per wave and ply) and folded into the global counters by one lane at the end.
+template <int WT>
+__global__ void __launch_bounds__(64)
+k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed, uint64_t step0,
+                 int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, unsigned long long* stats) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < N;
+  const int64_t ii = live ? i : N - 1;  // idle lanes shadow the last env, never store
+  MnkEnv<WT> e;
+  env_load<WT>(e, planes, meta, N, g.W, ii);
+  const uint64_t env = (uint64_t)(env_id0 + ii);
+  unsigned long long n_done = 0, n_black = 0, n_white = 0, n_draw = 0;
+  uint32_t len_sum = 0;
+  Philox4 blk = mnk_rng_block(seed, env, step0 >> 2, MNK_STREAM_MOVE);
+  for (int t = 0; t < T; ++t) {
+    const uint64_t step = step0 + (uint64_t)t;
+    if (t > 0 && (step & 3) == 0) blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
+    const uint32_t x = philox_word(blk, (uint32_t)(step & 3));
+    if (rec_planes && live) {
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int w = 0; w < WT; ++w)
+          if (w < g.W) rec_planes[(((int64_t)t * 2 + pl) * g.W + w) * N + i] = e.p[pl][w];
+    }
+    const uint32_t side = e.meta & 1u;
+    const int a = env_pick_legal<WT>(g, e, x);
+    const MnkPly ply = env_play<WT>(g, e, a, false);
+    if (rec_meta && live)
+      rec_meta[(int64_t)t * N + i] = (uint32_t)a | ((ply.win ? 1u : 0u) << MNK_REC_REWARD_SHIFT) |
+                                     ((ply.done ? 1u : 0u) << MNK_REC_DONE_BIT) | (side << MNK_REC_SIDE_BIT);
+    const bool fin = ply.done && live;
+    n_done += __popcll(__ballot(fin));
+    n_black += __popcll(__ballot(fin && ply.win && side == 0));
+    n_white += __popcll(__ballot(fin && ply.win && side == 1));
+    n_draw += __popcll(__ballot(fin && !ply.win));
+    if (fin) len_sum += e.meta >> 1;
+    if (ply.done) env_clear<WT>(e);  // env.reset(nonzero(done)) :34-44
+  }
+  if (live) env_store<WT>(e, planes, meta, N, g.W, i);
+  if (stats) {
+    unsigned long long ls = len_sum;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ls += __shfl_down(ls, off, 64);
+    if ((threadIdx.x & 63) == 0) {
+      if (n_done) atomicAdd(&stats[0], n_done);
+      if (n_black) atomicAdd(&stats[1], n_black);
+      if (n_white) atomicAdd(&stats[2], n_white);
+      if (n_draw) atomicAdd(&stats[3], n_draw);
+      if (ls) atomicAdd(&stats[4], ls);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ fused self-play step
+// selfplay/torch_self_play_wrapper.py:32-67 as fixed-shape masked kernels.  The reference
+// builds nonzero() index lists (two host syncs each) for "envs to reset", "envs to play" and
+// "envs where the opponent replies"; here every env carries those three facts as bits.
+struct SpAgent {
+  float reward;
+  bool term, was_reset, need_opp;
+};
+
+// wrapper:39-63 up to (not including) the opponent's reply, for one env
+template <int WT>
+__device__ __forceinline__ SpAgent sp_agent_half(const MnkGeom& g, MnkEnv<WT>& e, int64_t action, bool pending,
+                                                 int64_t& side, const int64_t* forced_side, uint64_t seed,
+                                                 uint64_t step, uint64_t env, int64_t i, int32_t* err) {
+  SpAgent a;
+  a.reward = 0.0f; a.term = false; a.was_reset = pending;
+  if (pending) {
+    env_clear<WT>(e);  // wrapper:41 env.reset(reset_idxs)
+    side = forced_side ? (forced_side[i] & 1) : (int64_t)(mnk_rand_u32(seed, env, step, MNK_STREAM_SIDE) >> 31);  // :43-45
+  } else {
+    const MnkPly ply = env_play<WT>(g, e, action, false);  // :51
+    if (ply.err) mnk_report(err, ply.err, i);
+    a.reward = ply.win ? 1.0f : 0.0f;  // :53
+    a.term = ply.done;                 // :54
+  }
+  // :46 / :56-59 -> _opponent_move_if_needed: reply where it is not the agent's turn (:74-77)
+  a.need_opp = (a.was_reset || !a.term) && ((int64_t)(e.meta & 1u) != side);
+  return a;
+}
+
+template <int WT>
+__global__ void __launch_bounds__(256)
+k_selfplay_pre(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions,
+               const uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
+               uint64_t step, int64_t env_id0, float* rewards, uint8_t* terminated, uint8_t* sp_flags,
+               float* opp_obs, uint8_t* opp_mask, int32_t* err, int vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int B = blockDim.x, tid = threadIdx.x;
+  const int64_t env0 = (int64_t)blockIdx.x * B;
+  const int64_t i = env0 + tid;
+  const bool emit = opp_obs || opp_mask;
+  MnkStage st = mnk_stage_carve(lds_raw, g, B);
+  if (emit) mnk_stage_tables(st, g, B, tid, B);
+  if (i < N) {
+    MnkEnv<WT> e;
+    env_load<WT>(e, planes, meta, N, g.W, i);
+    int64_t side = agent_side[i];
+    const bool pend = pending[i] != 0;
+    const SpAgent a = sp_agent_half<WT>(g, e, actions[i], pend, side, forced_side, seed, step,
+                                        (uint64_t)(env_id0 + i), i, err);
+    env_store<WT>(e, planes, meta, N, g.W, i);
+    if (pend) agent_side[i] = side;
+    rewards[i] = a.reward;
+    terminated[i] = a.term ? 1 : 0;
+    sp_flags[i] = (a.need_opp ? MNK_SP_NEED_OPP : 0u) | (a.was_reset ? MNK_SP_WAS_RESET : 0u);
+    if (emit) {
+      // wrapper:83-89: the mover sees itself in channel 0
+      const bool white_to_move = (e.meta & 1u) != 0;
+      if (white_to_move) mnk_stage_put<WT>(st, g, B, tid, e.p[1], e.p[0], !a.need_opp);
+      else mnk_stage_put<WT>(st, g, B, tid, e.p[0], e.p[1], !a.need_opp);
+    }
+  }
+  if (emit) {
+    __syncthreads();
+    const int64_t left = N - env0;
+    const int nb = left < B ? (int)left : B;
+    if (opp_obs) mnk_emit_obs(st, g, nb, opp_obs + env0 * 2 * g.C, vec_ok & 1, tid, B);
+    if (opp_mask) mnk_emit_mask(st, g, nb, opp_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, B);
+  }
+}
+
+template <int WT>
+__global__ void __launch_bounds__(256)
+k_selfplay_post(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* opp_actions,
+                const uint8_t* sp_flags, const int64_t* agent_side, float* rewards, uint8_t* terminated,
+                uint8_t* pending, float* obs, uint8_t* legal_mask, int32_t* err, int vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int B = blockDim.x, tid = threadIdx.x;
+  const int64_t env0 = (int64_t)blockIdx.x * B;
+  const int64_t i = env0 + tid;
+  const bool emit = obs || legal_mask;
+  MnkStage st = mnk_stage_carve(lds_raw, g, B);
+  if (emit) mnk_stage_tables(st, g, B, tid, B);
+  if (i < N) {
+    MnkEnv<WT> e;
+    env_load<WT>(e, planes, meta, N, g.W, i);
+    const uint32_t f = sp_flags[i];
+    float rew = rewards[i];
+    bool term = terminated[i] != 0;
+    if (f & MNK_SP_NEED_OPP) {
+      const MnkPly ply = env_play<WT>(g, e, opp_actions[i], false);  // wrapper:96
+      if (ply.err) mnk_report(err, ply.err, i);
+      else env_store<WT>(e, planes, meta, N, g.W, i);
+      if (!(f & MNK_SP_WAS_RESET)) {  // :46 ignores the reply's outcome after a reset
+        rew -= ply.win ? 1.0f : 0.0f;  // :62
+        term = ply.done;               // :63
+      }
+      rewards[i] = rew;
+      terminated[i] = term ? 1 : 0;
+    }
+    pending[i] = term ? 1 : 0;  // :65
+    if (emit) {
+      if (agent_side[i] == 1) mnk_stage_put<WT>(st, g, B, tid, e.p[1], e.p[0], true);  // :104-106
+      else mnk_stage_put<WT>(st, g, B, tid, e.p[0], e.p[1], true);
+    }
+  }
+  if (emit) {
+    __syncthreads();
+    const int64_t left = N - env0;
+    const int nb = left < B ? (int)left : B;
+    if (obs) mnk_emit_obs(st, g, nb, obs + env0 * 2 * g.C, vec_ok & 1, tid, B);
+    if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, B);
+  }
+}
+
+// the whole wrapper.step in one launch when the opponent is RandomPolicy (policy.py:13-29)
+template <int WT>
+__global__ void __launch_bounds__(256)
+k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions,
+                       uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
+                       uint64_t step, int64_t env_id0, float* rewards, uint8_t* terminated, float* obs,
+                       uint8_t* legal_mask, int32_t* err, int vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int B = blockDim.x, tid = threadIdx.x;
+  const int64_t env0 = (int64_t)blockIdx.x * B;
+  const int64_t i = env0 + tid;
+  const bool emit = obs || legal_mask;
+  MnkStage st = mnk_stage_carve(lds_raw, g, B);
+  if (emit) mnk_stage_tables(st, g, B, tid, B);
+  if (i < N) {
+    MnkEnv<WT> e;
+    env_load<WT>(e, planes, meta, N, g.W, i);
+    int64_t side = agent_side[i];
+    const bool pend = pending[i] != 0;
+    const uint64_t env = (uint64_t)(env_id0 + i);
+    SpAgent a = sp_agent_half<WT>(g, e, actions[i], pend, side, forced_side, seed, step, env, i, err);
+    if (a.need_opp) {
+      const int oa = env_pick_legal<WT>(g, e, mnk_rand_u32(seed, env, step, MNK_STREAM_OPP));
+      const MnkPly ply = env_play<WT>(g, e, oa, false);
+      if (!a.was_reset) {
+        a.reward -= ply.win ? 1.0f : 0.0f;
+        a.term = ply.done;
+      }
+    }
+    env_store<WT>(e, planes, meta, N, g.W, i);
+    if (pend) agent_side[i] = side;
+    rewards[i] = a.reward;
+    terminated[i] = a.term ? 1 : 0;
+    pending[i] = a.term ? 1 : 0;
+    if (emit) {
+      if (side == 1) mnk_stage_put<WT>(st, g, B, tid, e.p[1], e.p[0], true);
+      else mnk_stage_put<WT>(st, g, B, tid, e.p[0], e.p[1], true);
+    }
+  }
+  if (emit) {
+    __syncthreads();
+    const int64_t left = N - env0;
+    const int nb = left < B ? (int)left : B;
+    if (obs) mnk_emit_obs(st, g, nb, obs + env0 * 2 * g.C, vec_ok & 1, tid, B);
+    if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, B);
+  }
+}
+
+// ------------------------------------------------------------------ masked categorical head + draw
+// alg/architectures/cnn.py:69-79 fused with Categorical.sample (policy.py:46-52).  One wave per
+// row: lanes stride over the C cells, a butterfly (shuffle-xor) argmax picks the winner of the
+// Gumbel-perturbed masked logits; ties go to the lowest cell like torch.argmax.
+__device__ __forceinline__ void wave_argmax(float& v, int& idx) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(v, off, 64);
+    const int oi = __shfl_xor(idx, off, 64);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(64)
+k_sample_logits(const float* logits, const uint8_t* mask, int64_t N, int C, uint64_t seed, uint64_t step,
+                int64_t env_id0, int deterministic, int64_t* actions, float* logp) {
+  const int64_t i = blockIdx.x;
+  if (i >= N) return;
+  const int lane = threadIdx.x;
+  const float* lrow = logits + i * C;
+  const uint8_t* mrow = mask + i * C;
+  const float NEG = -__builtin_huge_valf();
+  // does the row have a legal cell at all?  (cnn.py:76-77: all-masked -> zeros -> uniform)
+  int any = 0;
+  for (int c = lane; c < C; c += 64) any |= mrow[c];
+  const bool none_legal = __ballot(any != 0) == 0ull;
+  const uint64_t env = (uint64_t)(env_id0 + i);
+  const uint32_t CB = (uint32_t)((C + 3) >> 2);
+  float best = NEG, vmax = NEG;
+  int besti = 0x7fffffff;
+  // lane handles groups of 4 consecutive cells: one Philox block per group
+  for (int c0 = lane * 4; c0 < C; c0 += 256) {
+    Philox4 blk;
+    if (!deterministic) blk = mnk_rng_block(seed, env, step * (uint64_t)CB + (uint64_t)(c0 >> 2), MNK_STREAM_GUMBEL);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + j;
+      if (c < C) {
+        const bool legal = none_legal || mrow[c] != 0;
+        const float l = none_legal ? 0.0f : lrow[c];
+        if (legal) {
+          vmax = fmaxf(vmax, l);
+          float score = l;
+          if (!deterministic) {
+            const float u = ((float)(blk.v[j] >> 8) + 0.5f) * 5.9604644775390625e-08f;  // (0,1)
+            score = l - logf(-logf(u));
+          }
+          if (score > best || (score == best && c < besti)) { best = score; besti = c; }
+        }
+      }
+    }
+  }
+  wave_argmax(best, besti);
+  if (logp) {
+    vmax = wave_max(vmax);
+    float se = 0.0f;
+    for (int c = lane; c < C; c += 64) {
+      const bool legal = none_legal || mrow[c] != 0;
+      if (legal) se += expf((none_legal ? 0.0f : lrow[c]) - vmax);
+    }
+    se = wave_sum(se);
+    if (lane == 0) logp[i] = (none_legal ? 0.0f : lrow[besti]) - vmax - logf(se);
+  }
+  if (lane == 0) actions[i] = besti;
+}
+
+// ------------------------------------------------------------------ records -> RolloutBuffer layout
+template <int WT>
+__global__ void __launch_bounds__(256)
+k_unpack_records(MnkGeom g, const uint64_t* rec_planes, const uint32_t* rec_meta, int64_t N, float* obs,
+                 uint8_t* masks, int64_t* actions, float* rewards, uint8_t* dones, int vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int B = blockDim.x, tid = threadIdx.x;
+  const int64_t t = blockIdx.y;
+  const int64_t env0 = (int64_t)blockIdx.x * B;
+  const int64_t i = env0 + tid;
+  const bool emit = obs || masks;
+  MnkStage st = mnk_stage_carve(lds_raw, g, B);
+  if (emit) mnk_stage_tables(st, g, B, tid, B);
+  if (i < N) {
+    const uint32_t mw = rec_meta[t * N + i];
+    if (actions) actions[t * N + i] = (int64_t)(mw & MNK_REC_ACTION_MASK);
+    if (rewards) rewards[t * N + i] = (float)(int8_t)((mw >> MNK_REC_REWARD_SHIFT) & 0xFFu);
+    if (dones) dones[t * N + i] = (uint8_t)((mw >> MNK_REC_DONE_BIT) & 1u);
+    if (emit) {
+      uint64_t a[WT], b[WT];
+      const bool flip = ((mw >> MNK_REC_SIDE_BIT) & 1u) != 0;  // the mover sees itself in channel 0
+#pragma unroll
+      for (int w = 0; w < WT; ++w) {
+        const uint64_t p0 = w < g.W ? rec_planes[((t * 2 + 0) * g.W + w) * N + i] : 0ull;
+        const uint64_t p1 = w < g.W ? rec_planes[((t * 2 + 1) * g.W + w) * N + i] : 0ull;
+        a[w] = flip ? p1 : p0;
+        b[w] = flip ? p0 : p1;
+      }
+      mnk_stage_put<WT>(st, g, B, tid, a, b, false);
+    }
+  }
+  if (emit) {
+    __syncthreads();
+    const int64_t left = N - env0;
+    const int nb = left < B ? (int)left : B;
+    const int64_t row0 = t * N + env0;
+    if (obs) mnk_emit_obs(st, g, nb, obs + row0 * 2 * g.C, vec_ok & 1, tid, B);
+    if (masks) mnk_emit_mask(st, g, nb, masks + row0 * g.C, (vec_ok >> 1) & 1, tid, B);
+  }
+}
+
+// ------------------------------------------------------------------ GAE (alg/rollout_buffer.py:60-80)
+// one lane per env, reverse scan over T; every access is coalesced over the env axis.  The
+// operation order and the f32 roundings are the reference's (built with -ffp-contract=off).
+__global__ void __launch_bounds__(256)
+k_gae(const float* rewards, const float* values, const uint8_t* dones, const float* last_values, int64_t N, int T,
+      float gamma, float gamma_lambda, float* advantages, float* returns) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float run = 0.0f;
+  float next_v = last_values[i];
+  for (int t = T - 1; t >= 0; --t) {
+    const int64_t o = (int64_t)t * N + i;
+    const float v = values[o];
+    const float nonterm = 1.0f - (dones[o] ? 1.0f : 0.0f);           // :72
+    const float delta = rewards[o] + gamma * next_v * nonterm - v;    // :74
+    run = delta + gamma_lambda * nonterm * run;                       // :75
+    advantages[o] = run;                                              // :77
+    returns[o] = run + v;                                             // :79
+    next_v = v;
+  }
+}
+
+// ================================================================== C ABI
+extern "C" {
+
+int mnk_abi_version(void) { return MNK_ABI_VERSION; }
+
+int mnk_state_words(int m, int n) {
+  if (m < 1 || n < 1 || n > 61) return 0;
+  const int W = (m * (n + 1) + 63) / 64;
+  return W <= MNK_MAX_W ? W : 0;
+}
+
+int mnk_geometry_supported(int m, int n, int k) {
+  MnkGeom g;
+  return mnk_check_geom(m, n, k, &g) == MNK_OK ? 1 : 0;
+}
+
+const char* mnk_last_launch_error(void) { return g_launch_err; }
+
+int mnk_reset_all(uint64_t* planes, uint32_t* meta, int64_t N, int W, void* stream) {
+  if (!planes || !meta || N < 0 || W < 1 || W > MNK_MAX_W) return MNK_EINVAL;
+  if (N == 0) return MNK_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(planes, 0, (size_t)2 * W * N * sizeof(uint64_t), s) != hipSuccess) return mnk_launch_status("reset_all");
+  if (hipMemsetAsync(meta, 0, (size_t)N * sizeof(uint32_t), s) != hipSuccess) return mnk_launch_status("reset_all");
+  return MNK_OK;
+}
+
+int mnk_reset_idx(uint64_t* planes, uint32_t* meta, int64_t N, int W, const int64_t* idx, int64_t R, int32_t* err,
+                  void* stream) {
+  if (!planes || !meta || N < 0 || R < 0 || W < 1 || W > MNK_MAX_W || (R > 0 && !idx)) return MNK_EINVAL;
+  if (R == 0 || N == 0) return MNK_OK;
+  const int B = 256;
+  hipLaunchKernelGGL(k_reset_idx, dim3((unsigned)((R + B - 1) / B)), dim3(B), 0, (hipStream_t)stream, planes, meta, N,
+                     W, idx, R, err);
+  return mnk_launch_status("reset_idx");
+}
+
+int mnk_reset_mask(uint64_t* planes, uint32_t* meta, int64_t N, int W, const uint8_t* mask, void* stream) {
+  if (!planes || !meta || !mask || N < 0 || W < 1 || W > MNK_MAX_W) return MNK_EINVAL;
+  if (N == 0) return MNK_OK;
+  const int B = 256;
+  hipLaunchKernelGGL(k_reset_mask, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, (hipStream_t)stream, planes, meta, N,
+                     W, mask);
+  return mnk_launch_status("reset_mask");
+}
+
+int mnk_observe(const uint64_t* planes, const uint32_t* meta, int64_t N, int m, int n, const int64_t* flip_side,
+                float* obs, uint8_t* legal_mask, int fix_empty_mask, void* stream) {
+  (void)meta;
+  MnkGeom g;
+  int rc = mnk_check_geom(m, n, 1, &g);
+  if (rc != MNK_OK) return rc;
+  if (!planes || N < 0) return MNK_EINVAL;
+  if (N == 0 || (!obs && !legal_mask)) return MNK_OK;
+  const int B = mnk_block_envs(N);
+  const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
+  const size_t lds = mnk_stage_bytes(g.W, g.C, B);
+  const dim3 grid((unsigned)((N + B - 1) / B));
+  MNK_DISPATCH_W(g.W, hipLaunchKernelGGL(k_observe<WT>, grid, dim3(B), lds, (hipStream_t)stream, g, planes, N,
+                                         flip_side, obs, legal_mask, fix_empty_mask, vec_ok));
+  return mnk_launch_status("observe");
+}
+
+int mnk_unpack_boards(const uint64_t* planes, float* boards, int64_t N, int m, int n, void* stream) {
+  if (!boards) return MNK_EINVAL;
+  return mnk_observe(planes, nullptr, N, m, n, nullptr, boards, nullptr, 0, stream);
+}
+
+int mnk_pack_boards(const float* boards, uint64_t* planes, int64_t N, int m, int n, void* stream) {
+  MnkGeom g;
+  int rc = mnk_check_geom(m, n, 1, &g);
+  if (rc != MNK_OK) return rc;
+  if (!boards || !planes || N < 0) return MNK_EINVAL;
+  if (N == 0) return MNK_OK;
+  const int B = 64;
+  hipLaunchKernelGGL(k_pack_boards, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, (hipStream_t)stream, g, boards,
+                     planes, N);
+  return mnk_launch_status("pack_boards");
+}
+
+int mnk_step(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const int64_t* actions,
+             const int64_t* active_idx, int64_t A, float* rewards, uint8_t* dones, uint8_t* legal_mask, float* obs,
+             int32_t* err, uint32_t flags, void* stream) {
+  MnkGeom g;
+  int rc = mnk_check_geom(m, n, k, &g);
+  if (rc != MNK_OK) return rc;
+  if (!planes || !meta || !rewards || !dones || N < 0 || A < 0 || (A > 0 && !actions)) return MNK_EINVAL;
+  if (!active_idx && A != N) return MNK_EINVAL;
+  if (N == 0) return MNK_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (!active_idx) {
+    const int B = mnk_block_envs(N);
+    const bool emit = legal_mask || obs;
+    const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
+    const size_t lds = emit ? mnk_stage_bytes(g.W, g.C, B) : 0;
+    const dim3 grid((unsigned)((N + B - 1) / B));
+    MNK_DISPATCH_W(g.W, hipLaunchKernelGGL(k_step_full<WT>, grid, dim3(B), lds, s, g, planes, meta, N, actions,
+                                           rewards, dones, legal_mask, obs, err, flags, vec_ok));
+    return mnk_launch_status("step");
+  }
+  // subset: full-size zero rewards / dones (:75, :79), scatter the active ones, then a full observe
+  if (hipMemsetAsync(rewards, 0, (size_t)N * sizeof(float), s) != hipSuccess) return mnk_launch_status("step_subset");
+  if (hipMemsetAsync(dones, 0, (size_t)N, s) != hipSuccess) return mnk_launch_status("step_subset");
+  if (A > 0) {
+    const int B = 64;
+    const dim3 grid((unsigned)((A + B - 1) / B));
+    MNK_DISPATCH_W(g.W, hipLaunchKernelGGL(k_step_subset<WT>, grid, dim3(B), 0, s, g, planes, meta, N, actions,
+                                           active_idx, A, rewards, dones, err, flags));
+    rc = mnk_launch_status("step_subset");
+    if (rc != MNK_OK) return rc;
+  }
+  if (legal_mask || obs) return mnk_observe(planes, meta, N, m, n, nullptr, obs, legal_mask, 0, stream);
+  return MNK_OK;
+}
+
+int mnk_sample_legal(const uint64_t* planes, int64_t N, int m, int n, uint64_t seed, uint64_t step, int64_t env_id0,
+                     int stream_id, int64_t* actions, void* stream) {
+  MnkGeom g;
+  int rc = mnk_check_geom(m, n, 1, &g);
+  if (rc != MNK_OK) return rc;
+  if (!planes || !actions || N < 0 || stream_id < 0 || stream_id > 255) return MNK_EINVAL;
+  if (N == 0) return MNK_OK;
+  const int B = 64;
+  const dim3 grid((unsigned)((N + B - 1) / B));
+  MNK_DISPATCH_W(g.W, hipLaunchKernelGGL(k_sample_legal<WT>, grid, dim3(B), 0, (hipStream_t)stream, g, planes, N, seed,
+                                         step, env_id0, (uint32_t)stream_id, actions));
+  return mnk_launch_status("sample_legal");
+}
+
+int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, int T, uint64_t seed,
+                       uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
+                       void* stream) {
+  MnkGeom g;
+  int rc = mnk_check_geom(m, n, k, &g);
+  if (rc != MNK_OK) return rc;
+  if (!planes || !meta || N < 0 || T < 0) return MNK_EINVAL;
+  if (N == 0 || T == 0) return MNK_OK;
+  const int B = 64;
+  const dim3 grid((unsigned)((N + B - 1) / B));
+  MNK_DISPATCH_W(g.W, hipLaunchKernelGGL(k_rollout_random<WT>, grid, dim3(B), 0, (hipStream_t)stream, g, planes, meta,
+                                         N, T, seed, step0, env_id0, rec_planes, rec_meta,
+                                         (unsigned long long*)stats));
+  return mnk_launch_status("rollout_random");
+}
+
+int mnk_selfplay_pre(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const int64_t* actions,
+                     const uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
+                     uint64_t step, int64_t env_id0, float* rewards, uint8_t* terminated, uint8_t* sp_flags,
+                     float* opp_obs, uint8_t* opp_mask, int32_t* err, void* stream) {
+  MnkGeom g;
+  int rc = mnk_check_geom(m, n, k, &g);
+  if (rc != MNK_OK) return rc;
+  if (!planes || !meta || !actions || !pending || !agent_side || !rewards || !terminated || !sp_flags || N < 0)
+    return MNK_EINVAL;
+  if (N == 0) return MNK_OK;
+  const int B = mnk_block_envs(N);
+  const bool emit = opp_obs || opp_mask;
+  const int vec_ok = (aligned16(opp_obs) ? 1 : 0) | (aligned16(opp_mask) ? 2 : 0);
+  const size_t lds = emit ? mnk_stage_bytes(g.W, g.C, B) : 0;
+  const dim3 grid((unsigned)((N + B - 1) / B));
+  MNK_DISPATCH_W(g.W, hipLaunchKernelGGL(k_selfplay_pre<WT>, grid, dim3(B), lds, (hipStream_t)stream, g, planes, meta,
+                                         N, actions, pending, agent_side, forced_side, seed, step, env_id0, rewards,
+                                         terminated, sp_flags, opp_obs, opp_mask, err, vec_ok));
+  return mnk_launch_status("selfplay_pre");
+}
+
+int mnk_selfplay_post(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const int64_t* opp_actions,
+                      const uint8_t* sp_flags, const int64_t* agent_side, float* rewards, uint8_t* terminated,
+                      uint8_t* pending, float* obs, uint8_t* legal_mask, int32_t* err, void* stream) {
+  MnkGeom g;
+  int rc = mnk_check_geom(m, n, k, &g);
+  if (rc != MNK_OK) return rc;
+  if (!planes || !meta || !opp_actions || !sp_flags || !agent_side || !rewards || !terminated || !pending || N < 0)
+    return MNK_EINVAL;
+  if (N == 0) return MNK_OK;
+  const int B = mnk_block_envs(N);
+  const bool emit = obs || legal_mask;
+  const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
+  const size_t lds = emit ? mnk_stage_bytes(g.W, g.C, B) : 0;
+  const dim3 grid((unsigned)((N + B - 1) / B));
+  MNK_DISPATCH_W(g.W, hipLaunchKernelGGL(k_selfplay_post<WT>, grid, dim3(B), lds, (hipStream_t)stream, g, planes,
+                                         meta, N, opp_actions, sp_flags, agent_side, rewards, terminated, pending, obs,
+                                         legal_mask, err, vec_ok));
+  return mnk_launch_status("selfplay_post");
+}
+
+int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const int64_t* actions,
+                             uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
+                             uint64_t step, int64_t env_id0, float* rewards, uint8_t* terminated, float* obs,
+                             uint8_t* legal_mask, int32_t* err, void* stream) {
+  MnkGeom g;
+  int rc = mnk_check_geom(m, n, k, &g);
+  if (rc != MNK_OK) return rc;
+  if (!planes || !meta || !actions || !pending || !agent_side || !rewards || !terminated || N < 0) return MNK_EINVAL;
+  if (N == 0) return MNK_OK;
+  const int B = mnk_block_envs(N);
+  const bool emit = obs || legal_mask;
+  const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
+  const size_t lds = emit ? mnk_stage_bytes(g.W, g.C, B) : 0;
+  const dim3 grid((unsigned)((N + B - 1) / B));
+  MNK_DISPATCH_W(g.W, hipLaunchKernelGGL(k_selfplay_step_random<WT>, grid, dim3(B), lds, (hipStream_t)stream, g,
+                                         planes, meta, N, actions, pending, agent_side, forced_side, seed, step,
+                                         env_id0, rewards, terminated, obs, legal_mask, err, vec_ok));
+  return mnk_launch_status("selfplay_step_random");
+}
+
+int mnk_sample_logits(const float* logits, const uint8_t* mask, int64_t N, int C, uint64_t seed, uint64_t step,
+                      int64_t env_id0, int deterministic, int64_t* actions, float* logp, void* stream) {
+  if (!logits || !mask || !actions || N < 0 || C < 1 || C > 65535) return MNK_EINVAL;
+  if (N == 0) return MNK_OK;
+  if (N > 0x7fffffffLL) return MNK_EINVAL;
+  hipLaunchKernelGGL(k_sample_logits, dim3((unsigned)N), dim3(64), 0, (hipStream_t)stream, logits, mask, N, C, seed,
+                     step, env_id0, deterministic, actions, logp);
+  return mnk_launch_status("sample_logits");
+}
+
+int mnk_unpack_records(const uint64_t* rec_planes, const uint32_t* rec_meta, int64_t N, int T, int m, int n,
+                       float* obs, uint8_t* masks, int64_t* actions, float* rewards, uint8_t* dones, void* stream) {
+  MnkGeom g;
+  int rc = mnk_check_geom(m, n, 1, &g);
+  if (rc != MNK_OK) return rc;
+  if (!rec_meta || N < 0 || T < 0 || T > 65535 || ((obs || masks) && !rec_planes)) return MNK_EINVAL;
+  if (N == 0 || T == 0) return MNK_OK;
+  const int B = mnk_block_envs(N);
+  const bool emit = obs || masks;
+  // slabs start at row t*N + env0: 16-byte alignment of every slab needs N*rowbytes % 16 == 0 too
+  const bool obs_vec = aligned16(obs) && ((N * 2 * g.C * 4) % 16 == 0);
+  const bool mask_vec = aligned16(masks) && ((N * g.C) % 16 == 0);
+  const int vec_ok = (obs_vec ? 1 : 0) | (mask_vec ? 2 : 0);
+  const size_t lds = emit ? mnk_stage_bytes(g.W, g.C, B) : 0;
+  const dim3 grid((unsigned)((N + B - 1) / B), (unsigned)T);
+  MNK_DISPATCH_W(g.W, hipLaunchKernelGGL(k_unpack_records<WT>, grid, dim3(B), lds, (hipStream_t)stream, g, rec_planes,
+                                         rec_meta, N, obs, masks, actions, rewards, dones, vec_ok));
+  return mnk_launch_status("unpack_records");
+}
+
+int mnk_gae(const float* rewards, const float* values, const uint8_t* dones, const float* last_values, int64_t N,
+            int T, float gamma, float gamma_lambda, float* advantages, float* returns, void* stream) {
+  if (!rewards || !values || !dones || !last_values || !advantages || !returns || N < 0 || T < 0) return MNK_EINVAL;
+  if (N == 0 || T == 0) return MNK_OK;
+  const int B = 256;
+  hipLaunchKernelGGL(k_gae, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, (hipStream_t)stream, rewards, values, dones,
+                     last_values, N, T, gamma, gamma_lambda, advantages, returns);
+  return mnk_launch_status("gae");
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+"""ctypes binding of ``libmnk_hip.so`` (C ABI in ``include/mnk_hip.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There
+is no fallback: if the shared object is missing or a call fails, an exception is
+raised -- the product path never computes on the CPU.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmnk_hip.so")
+ABI_VERSION = 1
+
+MNK_OK = 0
+ERR_NONE, ERR_ACTION_RANGE, ERR_ILLEGAL_MOVE = 0, 1, 2
+STEP_STRICT = 1
+SP_NEED_OPP, SP_WAS_RESET = 1, 2
+STREAM_MOVE, STREAM_OPP, STREAM_SIDE, STREAM_GUMBEL = 0, 1, 2, 3
+REC_ACTION_MASK, REC_REWARD_SHIFT, REC_DONE_BIT, REC_SIDE_BIT = 0xFFFF, 16, 24, 25
+
+_vp, _i, _i64, _u64, _u32, _f = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint32,
+                                 ctypes.c_float)
+
+# name -> argtypes; restype is int unless noted.  Kept in step with include/mnk_hip.h
+# (tests/test_abi.py parses the header and compares).
+SIGNATURES = {
+    "mnk_abi_version": [],
+    "mnk_state_words": [_i, _i],
+    "mnk_geometry_supported": [_i, _i, _i],
+    "mnk_last_launch_error": [],
+    "mnk_reset_all": [_vp, _vp, _i64, _i, _vp],
+    "mnk_reset_idx": [_vp, _vp, _i64, _i, _vp, _i64, _vp, _vp],
+    "mnk_reset_mask": [_vp, _vp, _i64, _i, _vp, _vp],
+    "mnk_step": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    "mnk_observe": [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp],
+    "mnk_pack_boards": [_vp, _vp, _i64, _i, _i, _vp],
+    "mnk_unpack_boards": [_vp, _vp, _i64, _i, _i, _vp],
+    "mnk_sample_legal": [_vp, _i64, _i, _i, _u64, _u64, _i64, _i, _vp, _vp],
+    "mnk_sample_logits": [_vp, _vp, _i64, _i, _u64, _u64, _i64, _i, _vp, _vp, _vp],
+    "mnk_selfplay_pre": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _u64, _u64, _i64, _vp, _vp, _vp, _vp, _vp,
+                         _vp, _vp],
+    "mnk_selfplay_post": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mnk_selfplay_step_random": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _u64, _u64, _i64, _vp, _vp, _vp,
+                                 _vp, _vp, _vp],
+    "mnk_rollout_random": [_vp, _vp, _i64, _i, _i, _i, _i, _u64, _u64, _i64, _vp, _vp, _vp, _vp],
+    "mnk_unpack_records": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mnk_gae": [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp],
+}
+
+_STATUS = {-1: "invalid argument (null pointer / negative size)", -2: "unsupported board geometry",
+           -3: "kernel launch failed"}
+
+
+class MnkHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises MnkHipError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MnkHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for this path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header / library mismatch
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_char_p if name == "mnk_last_launch_error" else ctypes.c_int
+    if lib.mnk_abi_version() != ABI_VERSION:
+        raise MnkHipError(f"libmnk_hip.so ABI {lib.mnk_abi_version()} != binding ABI {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (or NULL for None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "mnk_hip: tensors handed to the C ABI must be contiguous"
+    return t.data_ptr()
+
+
+def stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != MNK_OK:
+        detail = _STATUS.get(rc, f"status {rc}")
+        if rc == -3:
+            detail += ": " + (lib.mnk_last_launch_error() or b"").decode()
+        raise MnkHipError(f"{name}: {detail}")
+    return rc
+
+
+def state_words(m, n):
+    return load().mnk_state_words(m, n)
+
+
+def geometry_supported(m, n, k):
+    return bool(load().mnk_geometry_supported(m, n, k))

@@ -1,0 +1,142 @@
+"""Fused random-policy rollout: the BASELINE.json workload as one kernel launch per chunk.
+
+The reference has no rollout driver for random play; the loop it runs is the one in
+SURVEY.md Appendix A -- ``RandomPolicy.act`` (``src/selfplay/policy.py:18-29``) ->
+``env.step`` (``src/env/torch_vector_mnk_env.py:55-84``) -> ``env.reset(nonzero(done))``
+(``:34-44``) -- about 45 eager launches and two host syncs per ply.  Here T plies of
+every env run inside ``mnk_rollout_random`` with the state in registers; what reaches
+HBM is the packed record of each ply:
+
+    planes  u64[T][2][W][N]   the board *before* the ply (absolute planes)
+    meta    u32[T][N]         action | reward << 16 | done << 24 | mover side << 25
+
+Envs are independent, so a node shards them by contiguous blocks: rank r owns global
+env ids [r*N, (r+1)*N) and the Philox key uses the global id, which makes the records
+independent of the number of GPUs.  ``gather()`` is the one exchange step: an
+all-gather of the packed records (RCCL over xGMI when the process group is ``nccl``).
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+import mnk_hip
+
+
+@dataclass
+class RolloutRecords:
+    planes: torch.Tensor  # int64 (u64 bits) [T, 2, W, N]
+    meta: torch.Tensor    # int32 (u32 bits) [T, N]
+
+    @property
+    def steps(self) -> int:
+        return self.meta.shape[0]
+
+    def actions(self) -> torch.Tensor:
+        return (self.meta & mnk_hip.REC_ACTION_MASK).to(torch.int64)
+
+    def rewards(self) -> torch.Tensor:
+        return ((self.meta >> mnk_hip.REC_REWARD_SHIFT) & 0xFF).to(torch.int8).to(torch.float32)
+
+    def dones(self) -> torch.Tensor:
+        return ((self.meta >> mnk_hip.REC_DONE_BIT) & 1).to(torch.bool)
+
+    def sides(self) -> torch.Tensor:
+        return ((self.meta >> mnk_hip.REC_SIDE_BIT) & 1).to(torch.int64)
+
+
+class RandomRollout:
+    """Drives ``mnk_rollout_random`` on one env shard.
+
+    ``env``: a ``TorchVectorMnkEnv``; ``seed``: Philox key; ``env_id0``: global id of
+    this shard's first env (rank * num_envs when sharded).
+    """
+
+    def __init__(self, env, seed: int = 0, env_id0: int = 0):
+        self.env = env
+        self.seed = int(seed)
+        self.env_id0 = int(env_id0)
+        self.step = 0  # plies played per env so far = Philox step counter
+        # [episodes finished, black wins, white wins, draws, sum of finished-episode lengths]
+        self.stats = torch.zeros(5, dtype=torch.int64, device=env._dev)
+
+    def alloc(self, steps: int) -> RolloutRecords:
+        env = self.env
+        return RolloutRecords(
+            planes=torch.empty((steps, 2, env.words, env.num_envs), dtype=torch.int64, device=env._dev),
+            meta=torch.empty((steps, env.num_envs), dtype=torch.int32, device=env._dev),
+        )
+
+    def run(self, steps: int, out: Optional[RolloutRecords] = None, record: bool = True) -> Optional[RolloutRecords]:
+        """Plays ``steps`` random plies on every env (finished games restart in place).
+        One launch; returns the records (written into ``out`` when given)."""
+        env = self.env
+        if record and out is None:
+            out = self.alloc(steps)
+        if record:
+            assert out.meta.shape == (steps, env.num_envs) and out.planes.shape[0] == steps
+        if env.num_envs and steps:
+            mnk_hip.call("mnk_rollout_random", mnk_hip.ptr(env._planes), mnk_hip.ptr(env._meta), env.num_envs,
+                         env.m, env.n, env.k, steps, self.seed, self.step, self.env_id0,
+                         mnk_hip.ptr(out.planes) if record else None, mnk_hip.ptr(out.meta) if record else None,
+                         mnk_hip.ptr(self.stats), env._stream())
+        self.step += steps
+        return out if record else None
+
+
+def gather_records(rec: RolloutRecords, group=None) -> RolloutRecords:
+    """All-gather of the packed records over the env axis: every rank ends up with
+    [T, 2, W, world*N] / [T, world*N], rank r's envs at columns [r*N, (r+1)*N).
+
+    Uses ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI on the GPUs, ``gloo`` in
+    the CPU tests).  The collective gathers rank-major buffers; the permute back to the
+    env-minor layout is a local copy.
+    """
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    if world == 1:
+        return rec
+    t, two, w, n = rec.planes.shape
+    planes_all = torch.empty((world, t, two, w, n), dtype=rec.planes.dtype, device=rec.planes.device)
+    meta_all = torch.empty((world, t, n), dtype=rec.meta.dtype, device=rec.meta.device)
+    dist.all_gather_into_tensor(planes_all, rec.planes.contiguous(), group=group)
+    dist.all_gather_into_tensor(meta_all, rec.meta.contiguous(), group=group)
+    planes = planes_all.permute(1, 2, 3, 0, 4).reshape(t, two, w, world * n)
+    meta = meta_all.permute(1, 0, 2).reshape(t, world * n)
+    return RolloutRecords(planes=planes.contiguous(), meta=meta.contiguous())
+
+
+def unpack_records(rec: RolloutRecords, env) -> dict:
+    """Packed records -> the field layout of the reference's ``RolloutBuffer``
+    (``alg/rollout_buffer.py:14-44``): observations f32 [T,N,2,m,n] from the mover's point of view,
+    action_masks bool [T,N,C], actions i64 [T,N], rewards f32 [T,N], dones bool [T,N].  One launch."""
+    t, n = rec.meta.shape
+    dev = rec.meta.device
+    out = {
+        "observations": torch.empty((t, n, 2, env.m, env.n), dtype=torch.float32, device=dev),
+        "action_masks": torch.empty((t, n, env.max_moves), dtype=torch.bool, device=dev),
+        "actions": torch.empty((t, n), dtype=torch.long, device=dev),
+        "rewards": torch.empty((t, n), dtype=torch.float32, device=dev),
+        "dones": torch.empty((t, n), dtype=torch.bool, device=dev),
+    }
+    if t and n:
+        mnk_hip.call("mnk_unpack_records", mnk_hip.ptr(rec.planes), mnk_hip.ptr(rec.meta), n, t, env.m, env.n,
+                     mnk_hip.ptr(out["observations"]), mnk_hip.ptr(out["action_masks"]), mnk_hip.ptr(out["actions"]),
+                     mnk_hip.ptr(out["rewards"]), mnk_hip.ptr(out["dones"]), mnk_hip.stream_ptr(dev))
+    return out
+
+
+def gae(rewards, values, dones, last_values, gamma: float = 0.99, gae_lambda: float = 0.95):
+    """Advantages and returns of ``RolloutBuffer.compute_advantages_and_returns``
+    (``alg/rollout_buffer.py:60-80``) in one launch; inputs [T,N] (+ [N]), f32 / bool on the GPU."""
+    t, n = rewards.shape
+    dev = rewards.device
+    adv = torch.empty((t, n), dtype=torch.float32, device=dev)
+    ret = torch.empty((t, n), dtype=torch.float32, device=dev)
+    if t and n:
+        mnk_hip.call("mnk_gae", mnk_hip.ptr(rewards.contiguous()), mnk_hip.ptr(values.contiguous()),
+                     mnk_hip.ptr(dones.contiguous()), mnk_hip.ptr(last_values.reshape(-1).contiguous()), n, t,
+                     float(gamma), float(gamma * gae_lambda), mnk_hip.ptr(adv), mnk_hip.ptr(ret),
+                     mnk_hip.stream_ptr(dev))
+    return adv, ret

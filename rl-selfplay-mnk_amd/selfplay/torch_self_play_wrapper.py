@@ -1,0 +1,142 @@
+"""MI355X drop-in for the reference's ``TorchSelfPlayWrapper``.
+
+Surface of ``/root/reference/src/selfplay/torch_self_play_wrapper.py:6-115``
+(SURVEY.md §8b): ``reset(seed, options) -> (obs, {})``, ``step(actions) ->
+(obs, rewards, terminated, truncated, {})`` with NEXT_STEP autoreset, the opponent
+replying inside ``step`` and zero-sum rewards; attributes ``env``, ``device``,
+``num_envs``, ``opponent_policy``, ``agent_side`` (i64), ``pending_resets`` (bool).
+
+What differs is how a step executes.  The reference builds ``nonzero`` index lists
+for "envs to reset", "envs to play" and "envs where the opponent replies" -- 8-10
+host synchronisations and 150-200 eager launches per step.  Here every env carries
+those facts as bits and one step is
+
+    mnk_selfplay_pre   reset-or-agent-ply, side draw, opponent's view   (1 launch)
+    opponent_policy.act(full batch)                                      (caller's torch code, same stream)
+    mnk_selfplay_post  opponent ply, zero-sum merge, agent's canonical view (1 launch)
+
+with no host synchronisation; with the built-in ``RandomPolicy`` as opponent the
+three collapse into the single launch ``mnk_selfplay_step_random``.
+
+Differences a caller can observe, both deliberate:
+  * the opponent policy is called ONCE per step on the full batch of N rows (rows that
+    need no reply carry their current position and their answer is ignored), where the
+    reference calls it up to twice on compacted subsets (wrapper:46 and :59).  A policy
+    whose action for a row depends only on that row is unaffected;
+  * fresh sides come from Philox keyed by (seed, env, step) instead of ``torch.randint``
+    on the global generator (wrapper:26, :43-45); ``force_sides`` replays a given stream.
+"""
+from typing import Optional
+
+import torch
+
+import mnk_hip
+from env.constants import PLAYER_BLACK, PLAYER_WHITE  # noqa: F401  (same import as the reference, wrapper:3)
+
+
+class TorchSelfPlayWrapper:
+    def __init__(self, env, seed: Optional[int] = None):
+        self.env = env
+        self.device = env.device
+        self.num_envs = env.num_envs
+        self._dev = env._dev
+
+        self.opponent_policy = None
+        self.agent_side = torch.zeros(self.num_envs, dtype=torch.long, device=self._dev)
+        self.pending_resets = torch.zeros(self.num_envs, dtype=torch.bool, device=self._dev)
+
+        self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        self.env_id0 = 0          # global id of env 0 (rank * num_envs when the env axis is sharded)
+        self.step_count = 0       # Philox step counter: one per reset()/step() call
+        self._forced_sides = None
+        self._flags = torch.zeros(self.num_envs, dtype=torch.uint8, device=self._dev)
+        self._no_actions = torch.zeros(self.num_envs, dtype=torch.long, device=self._dev)
+
+    def set_opponent(self, policy):  # reference wrapper:16-17
+        self.opponent_policy = policy
+
+    def force_sides(self, sides) -> None:
+        """Sides to hand out at the next (auto)reset instead of the Philox draw: an int, an
+        (N,) tensor, or None to go back to drawing.  Only envs that actually reset read it."""
+        if sides is None:
+            self._forced_sides = None
+        else:
+            t = torch.as_tensor(sides, device=self._dev).to(torch.long)
+            self._forced_sides = t.expand(self.num_envs).contiguous() if t.dim() == 0 else t.contiguous()
+
+    # ------------------------------------------------------------------ reference surface
+    def reset(self, seed=None, options=None):
+        """reference wrapper:19-30 (``seed`` is accepted and ignored there; here it re-keys Philox)"""
+        if seed is not None:
+            self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        forced = self._forced_sides
+        if options and "agent_side" in options:
+            t = torch.as_tensor(options["agent_side"], device=self._dev).to(torch.long)
+            forced = t.expand(self.num_envs).contiguous() if t.dim() == 0 else t.contiguous()
+        # a reset is a step in which every env is pending: boards cleared, sides handed out,
+        # the opponent opens wherever the agent is white, and its outcome is ignored (:28)
+        self.pending_resets.fill_(True)
+        obs, _, _, _, _ = self._advance(self._no_actions, forced)
+        return obs, {}
+
+    def step(self, actions: torch.Tensor):
+        """reference wrapper:32-67"""
+        a = torch.as_tensor(actions, device=self._dev).to(torch.long).reshape(-1).contiguous()
+        if a.numel() != self.num_envs:
+            raise IndexError(f"shape mismatch: {a.numel()} actions for {self.num_envs} envs")
+        return self._advance(a, self._forced_sides)
+
+    def get_agent_obs(self):
+        """reference wrapper:99-115: the agent's stones in channel 0, mask[.,0] forced on full boards"""
+        env = self.env
+        obs = torch.empty((self.num_envs, 2, env.m, env.n), dtype=torch.float32, device=self._dev)
+        mask = torch.empty((self.num_envs, env.max_moves), dtype=torch.bool, device=self._dev)
+        env.observe_into(obs, mask, flip_side=self.agent_side, fix_empty_mask=True)
+        return {"observation": obs, "action_mask": mask}
+
+    _get_canonical_obs = get_agent_obs
+
+    # ------------------------------------------------------------------ one fused step
+    def _advance(self, actions, forced):
+        env = self.env
+        n = self.num_envs
+        dev = self._dev
+        obs = torch.empty((n, 2, env.m, env.n), dtype=torch.float32, device=dev)
+        mask = torch.empty((n, env.max_moves), dtype=torch.bool, device=dev)
+        rewards = torch.empty(n, dtype=torch.float32, device=dev)
+        terminated = torch.empty(n, dtype=torch.bool, device=dev)
+        step = self.step_count
+        self.step_count += 1
+        opp = self.opponent_policy
+        if n == 0:
+            return {"observation": obs, "action_mask": mask}, rewards, terminated, torch.zeros_like(terminated), {}
+
+        if getattr(opp, "fused_uniform_random", False):
+            # RandomPolicy opponent: the whole step is one launch
+            mnk_hip.call("mnk_selfplay_step_random", mnk_hip.ptr(env._planes), mnk_hip.ptr(env._meta), n, env.m,
+                         env.n, env.k, mnk_hip.ptr(actions), mnk_hip.ptr(self.pending_resets),
+                         mnk_hip.ptr(self.agent_side), mnk_hip.ptr(forced), self.seed, step, self.env_id0,
+                         mnk_hip.ptr(rewards), mnk_hip.ptr(terminated), mnk_hip.ptr(obs), mnk_hip.ptr(mask),
+                         mnk_hip.ptr(env._err), env._stream())
+        else:
+            if opp is None:
+                raise RuntimeError("TorchSelfPlayWrapper: set_opponent(policy) before reset()/step()")
+            opp_obs = torch.empty((n, 2, env.m, env.n), dtype=torch.float32, device=dev)
+            opp_mask = torch.empty((n, env.max_moves), dtype=torch.bool, device=dev)
+            mnk_hip.call("mnk_selfplay_pre", mnk_hip.ptr(env._planes), mnk_hip.ptr(env._meta), n, env.m, env.n,
+                         env.k, mnk_hip.ptr(actions), mnk_hip.ptr(self.pending_resets), mnk_hip.ptr(self.agent_side),
+                         mnk_hip.ptr(forced), self.seed, step, self.env_id0, mnk_hip.ptr(rewards),
+                         mnk_hip.ptr(terminated), mnk_hip.ptr(self._flags), mnk_hip.ptr(opp_obs),
+                         mnk_hip.ptr(opp_mask), mnk_hip.ptr(env._err), env._stream())
+            with torch.no_grad():  # wrapper:91-94: one positional argument, no `deterministic`
+                opp_actions = opp.act({"observation": opp_obs, "action_mask": opp_mask})
+            opp_actions = torch.as_tensor(opp_actions, device=dev).to(torch.long).reshape(-1).contiguous()
+            if opp_actions.numel() != n:
+                raise IndexError(f"opponent policy returned {opp_actions.numel()} actions for {n} rows")
+            mnk_hip.call("mnk_selfplay_post", mnk_hip.ptr(env._planes), mnk_hip.ptr(env._meta), n, env.m, env.n,
+                         env.k, mnk_hip.ptr(opp_actions), mnk_hip.ptr(self._flags), mnk_hip.ptr(self.agent_side),
+                         mnk_hip.ptr(rewards), mnk_hip.ptr(terminated), mnk_hip.ptr(self.pending_resets),
+                         mnk_hip.ptr(obs), mnk_hip.ptr(mask), mnk_hip.ptr(env._err), env._stream())
+        if env.strict:
+            env.check_errors()
+        return {"observation": obs, "action_mask": mask}, rewards, terminated, torch.zeros_like(terminated), {}

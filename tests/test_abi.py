@@ -1,0 +1,76 @@
+"""CPU: the C-ABI library builds, loads, and exports exactly what include/mnk_hip.h declares.
+No compute calls here (no GPU in the build container)."""
+import os
+import re
+
+import pytest
+
+import __graft_entry__ as entry
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mnk_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    entry.build_hip()
+    entry._ensure_path()
+    import mnk_hip
+
+    return mnk_hip
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    decls = re.findall(r"\b(?:int|const char\*)\s+(mnk_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S)
+    out = {}
+    for name, args in decls:
+        args = args.strip()
+        out[name] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+    return out
+
+
+def test_header_declares_the_path():
+    decl = declared_functions()
+    for name in ("mnk_step", "mnk_observe", "mnk_reset_all", "mnk_reset_idx", "mnk_sample_legal",
+                 "mnk_rollout_random", "mnk_selfplay_pre", "mnk_selfplay_post", "mnk_sample_logits",
+                 "mnk_pack_boards", "mnk_unpack_boards", "mnk_unpack_records", "mnk_gae"):
+        assert name in decl
+
+
+def test_library_exports_every_declared_symbol(lib):
+    handle = lib.load()
+    decl = declared_functions()
+    assert set(decl) == set(lib.SIGNATURES), "binding and header disagree on the function list"
+    for name, nargs in decl.items():
+        assert hasattr(handle, name), f"{name} declared in mnk_hip.h but not exported"
+        assert len(lib.SIGNATURES[name]) == nargs, f"{name}: binding has {len(lib.SIGNATURES[name])} args, header {nargs}"
+    assert handle.mnk_abi_version() == lib.ABI_VERSION
+
+
+def test_geometry_queries_need_no_gpu(lib):
+    assert [lib.state_words(*s) for s in [(3, 3), (9, 9), (13, 13), (19, 19)]] == [1, 2, 3, 6]
+    assert lib.geometry_supported(9, 9, 5) and lib.geometry_supported(19, 19, 5) and lib.geometry_supported(22, 22, 5)
+    assert not lib.geometry_supported(3, 3, 4)      # k larger than the board
+    assert not lib.geometry_supported(30, 30, 5)    # beyond 512 bits per plane
+    assert lib.state_words(30, 30) == 0
+
+
+def test_argument_errors_are_reported_not_crashed(lib):
+    # null state pointers are rejected on the host before anything is enqueued
+    with pytest.raises(lib.MnkHipError):
+        lib.call("mnk_reset_all", None, None, 16, 2, None)
+    with pytest.raises(lib.MnkHipError):
+        lib.call("mnk_step", None, None, 16, 9, 9, 5, None, None, 16, None, None, None, None, None, 0, None)
+    with pytest.raises(lib.MnkHipError):
+        lib.call("mnk_rollout_random", None, None, 16, 40, 40, 5, 4, 0, 0, 0, None, None, None, None)
+
+
+def test_product_path_has_no_cpu_mode(lib):
+    from env.torch_vector_mnk_env import TorchVectorMnkEnv
+
+    with pytest.raises(RuntimeError, match="no CPU mode"):
+        TorchVectorMnkEnv(3, 3, 3, 4, device="cpu")
+    with pytest.raises(AssertionError):
+        TorchVectorMnkEnv(3, 3, 4, 4, device="cpu")  # reference env:9

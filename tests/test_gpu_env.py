@@ -1,0 +1,223 @@
+"""GPU parity: the HIP env (through the C ABI) against the golden vectors of the
+reference and against the oracle.  Bit-exact everywhere (integer / byte work)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox
+from oracle.env_torch import OracleVectorEnv
+from oracle.packing import pack_boards, pack_cells
+from oracle.rollout import random_rollout
+from replay import golden_files, play_scenario, replay_env_log
+from scenarios import SCENARIOS
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import __graft_entry__ as entry
+
+    entry.build_hip()
+    entry._ensure_path()
+    import mnk_hip
+    from env.torch_vector_mnk_env import TorchVectorMnkEnv
+    from selfplay.random_rollout import RandomRollout
+
+    mnk_hip.load()
+    assert torch.cuda.is_available()
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.lib, ns.Env, ns.Rollout = mnk_hip, TorchVectorMnkEnv, RandomRollout
+    return ns
+
+
+@pytest.mark.parametrize("idx", range(11))
+def test_env_oplog_matches_reference(hip, golden_dir, idx):
+    """G1 + G2: step / step_subset / reset(idx) op-logs recorded from the reference."""
+    log = np.load(golden_files(golden_dir, "env_")[idx])
+    m, n, k, nenv, _ = (int(v) for v in log["geom"])
+    replay_env_log(hip.Env(m, n, k, nenv, device=DEV), log)
+
+
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+def test_edge_scenarios_match_reference(hip, golden_dir, name):
+    """G4: poked positions, answers recorded from the reference."""
+    sc = SCENARIOS[name]
+    want = np.load(f"{golden_dir}/edges.npz")[name]
+    got = play_scenario(hip.Env(sc["m"], sc["n"], sc["k"], 1, device=DEV), sc)
+    assert np.array_equal(got, want)
+
+
+def test_reference_test_env_mechanics_win(hip):
+    """src/tests/test_mnk_integration.py:50-65, statement for statement."""
+    env = hip.Env(m=3, n=3, k=3, num_envs=1, device=DEV)
+    env.reset()
+    env.boards[0, 0, 0, 0] = 1
+    env.boards[0, 0, 0, 1] = 1
+    actions = torch.tensor([2], device=env.device)
+    _, rewards, dones = env.step(actions)
+    assert dones[0].item() is True
+    assert rewards[0].item() == 1.0
+
+
+def test_reference_test_env_illegal_move_strict(hip):
+    """src/tests/test_mnk_integration.py:68-81 -- fails on the reference as shipped (its validator is
+    dead code); here the check is opt-in (strict=True) and the default stays bit-compatible."""
+    env = hip.Env(m=3, n=3, k=3, num_envs=1, device=DEV, strict=True)
+    env.reset()
+    env.boards[0, 0, 0, 0] = 1
+    with pytest.raises(ValueError, match="Illegal Move"):
+        env.step(torch.tensor([0], device=env.device))
+    # the refused move left the env untouched
+    assert env.boards.sum().item() == 1.0 and int(env.move_counts[0]) == 0
+
+
+def test_out_of_range_action_is_reported(hip):
+    env = hip.Env(3, 3, 3, 4, device=DEV)
+    env.reset()
+    env.step(torch.tensor([0, 9, 1, 2], device=DEV))
+    with pytest.raises(IndexError):
+        env.check_errors()
+    # env 1 untouched, the others moved
+    assert env.move_counts.tolist() == [1, 0, 1, 1]
+
+
+def test_views_behave_like_dense_tensors(hip):
+    env = hip.Env(4, 6, 3, 8, device=DEV)
+    env.reset()
+    env.boards[2, 1, 3, 5] = 1.0
+    env.boards[3, 0] = torch.ones(4, 6)
+    assert env.boards.shape == (8, 2, 4, 6) and env.boards.dtype == torch.float32
+    assert env.boards[2].sum().item() == 1.0 and env.boards[3, 0].sum().item() == 24.0
+    assert float(torch.sum(env.boards)) == 25.0
+    assert env.boards[0].cpu().numpy().shape == (2, 4, 6)
+    env.current_player[torch.tensor([1, 5], device=DEV)] = 1
+    assert env.current_player.tolist() == [0, 1, 0, 0, 0, 1, 0, 0]
+    assert (env.current_player == 1).sum().item() == 2
+    idx = torch.tensor([5, 6], device=DEV)
+    env.current_player[idx] ^= 1
+    assert env.current_player.tolist() == [0, 1, 0, 0, 0, 0, 1, 0]
+    env.move_counts[4] = 7
+    assert env.move_counts.tolist() == [0, 0, 0, 0, 7, 0, 0, 0]
+    assert env.current_player.tolist() == [0, 1, 0, 0, 0, 0, 1, 0]  # untouched by the count write
+    mask = env.observe()["action_mask"]
+    assert mask[2].sum().item() == 23 and mask[3].sum().item() == 0
+    env.boards.zero_()
+    assert env.boards.sum().item() == 0.0
+    env.reset(torch.tensor([], dtype=torch.long, device=DEV))  # reset(empty) is a no-op
+
+
+@pytest.mark.parametrize("m,n,k,nenv,flip", [(3, 3, 3, 5, False), (9, 9, 5, 130, True), (19, 19, 5, 67, True),
+                                             (4, 6, 3, 64, True), (13, 13, 5, 1, False)])
+def test_observe_flip_and_empty_mask_fix(hip, m, n, k, nenv, flip):
+    """mnk_observe against numpy: absolute and canonical view (wrapper:99-112), ragged sizes."""
+    rng = np.random.default_rng(m * 100 + n)
+    dense = (rng.random((nenv, 2, m, n)) < 0.45).astype(np.float32)
+    dense[0] = 1.0  # a full board: no legal cell
+    env = hip.Env(m, n, k, nenv, device=DEV)
+    env.boards = torch.from_numpy(dense)
+    obs = env.observe()
+    assert np.array_equal(obs["observation"].cpu().numpy(), dense)
+    legal = ~(dense != 0).any(axis=1).reshape(nenv, m * n)
+    assert np.array_equal(obs["action_mask"].cpu().numpy(), legal)
+    if flip:
+        side = torch.from_numpy(rng.integers(0, 2, nenv)).to(DEV)
+        o = torch.empty((nenv, 2, m, n), dtype=torch.float32, device=DEV)
+        msk = torch.empty((nenv, m * n), dtype=torch.bool, device=DEV)
+        env.observe_into(o, msk, flip_side=side, fix_empty_mask=True)
+        want = dense.copy()
+        s = side.cpu().numpy() == 1
+        want[s] = want[s][:, ::-1]
+        assert np.array_equal(o.cpu().numpy(), want)
+        legal2 = legal.copy()
+        legal2[legal2.sum(axis=1) == 0, 0] = True
+        assert np.array_equal(msk.cpu().numpy(), legal2)
+
+
+@pytest.mark.parametrize("m,n,k,nenv", [(3, 3, 3, 64), (9, 9, 5, 1000), (19, 19, 5, 130), (13, 13, 5, 65),
+                                        (4, 6, 3, 33), (22, 22, 5, 16)])
+def test_sample_legal_matches_oracle(hip, m, n, k, nenv):
+    """mnk_sample_legal == oracle Philox + pick_legal, bit for bit (RandomPolicy stand-in)."""
+    rng = np.random.default_rng(7)
+    dense = (rng.random((nenv, 2, m, n)) < 0.35).astype(np.float32)
+    dense[1] = 1.0  # no legal cell -> uniform over all cells
+    env = hip.Env(m, n, k, nenv, device=DEV)
+    env.boards = torch.from_numpy(dense)
+    legal = ~(dense != 0).any(axis=1).reshape(nenv, m * n)
+    acts = torch.empty(nenv, dtype=torch.int64, device=DEV)
+    for step, stream, id0 in [(0, 0, 0), (5, 1, 1000), (2 ** 33 + 3, 2, 2 ** 32 + 5)]:
+        env.sample_legal_into(acts, seed=99, step=step, env_id0=id0, stream_id=stream)
+        x = philox.rand_u32(99, np.arange(id0, id0 + nenv, dtype=np.uint64), step, stream)
+        assert np.array_equal(acts.cpu().numpy(), philox.pick_legal(legal, x))
+
+
+@pytest.mark.parametrize("m,n,k,nenv,chunks", [(3, 3, 3, 64, (7, 9, 16)), (9, 9, 5, 333, (64, 31)),
+                                               (4, 6, 3, 100, (40,)), (13, 13, 5, 65, (120,)),
+                                               (19, 19, 5, 64, (200,)), (7, 9, 7, 70, (90,))])
+def test_rollout_matches_oracle(hip, m, n, k, nenv, chunks):
+    """mnk_rollout_random == oracle loop (sample -> step -> reset done), records, stats and final
+    state bit for bit; several launches continue the same Philox step counter."""
+    env = hip.Env(m, n, k, nenv, device=DEV)
+    roll = hip.Rollout(env, seed=5, env_id0=12345)
+    ora = OracleVectorEnv(m, n, k, nenv)
+    total = np.zeros(5, dtype=np.int64)
+    step0 = 0
+    for t in chunks:
+        rec = roll.run(t)
+        planes, meta, stats = random_rollout(ora, seed=5, step0=step0, steps=t, env_id0=12345)
+        total += stats
+        step0 += t
+        assert np.array_equal(rec.planes.cpu().numpy().view(np.uint64), planes)
+        assert np.array_equal(rec.meta.cpu().numpy().view(np.uint32), meta)
+        assert np.array_equal(roll.stats.cpu().numpy(), total)
+        assert np.array_equal(pack_boards(env.boards.cpu().numpy(), m, n), pack_boards(ora.boards.numpy(), m, n))
+        assert np.array_equal(env.current_player.cpu().numpy(), ora.current_player.numpy())
+        assert np.array_equal(env.move_counts.cpu().numpy(), ora.move_counts.numpy())
+
+
+def test_rollout_is_independent_of_sharding(hip):
+    """Global env ids key the RNG: two shards of 96 envs reproduce one batch of 192."""
+    m, n, k = 9, 9, 5
+    whole = hip.Rollout(hip.Env(m, n, k, 192, device=DEV), seed=3).run(70)
+    parts = [hip.Rollout(hip.Env(m, n, k, 96, device=DEV), seed=3, env_id0=96 * r).run(70) for r in (0, 1)]
+    assert torch.equal(whole.planes, torch.cat([p.planes for p in parts], dim=3))
+    assert torch.equal(whole.meta, torch.cat([p.meta for p in parts], dim=1))
+
+
+def test_full_size_rollout_properties(hip):
+    """BASELINE.json size (9x9x5, 65 536 envs): properties that need no oracle run --
+    every recorded action was legal on the recorded board, the next board is the previous one plus
+    that stone (or empty after a finished game), and the known random-play statistics hold
+    (mean 53.3 plies, 0.26 % draws)."""
+    m, n, k, nenv, steps = 9, 9, 5, 65536, 160
+    env = hip.Env(m, n, k, nenv, device=DEV)
+    roll = hip.Rollout(env, seed=1)
+    rec = roll.run(steps)
+    planes = rec.planes  # [T,2,W,N] int64
+    act = rec.actions()
+    bit = act + act // n
+    word, sh = bit >> 6, bit & 63
+    occ = planes[:, 0] | planes[:, 1]  # [T,W,N]
+    occ_at = torch.gather(occ, 1, word.unsqueeze(1)).squeeze(1)
+    assert not bool(((occ_at >> sh) & 1).any()), "an occupied cell was played"
+    side = rec.sides()
+    done = rec.dones()
+    stone = torch.zeros_like(planes[:-1])
+    one = (torch.ones_like(sh) << sh)[:-1]
+    for p in (0, 1):
+        for w in range(planes.shape[2]):
+            stone[:, p, w] = torch.where((side[:-1] == p) & (word[:-1] == w), one, torch.zeros_like(one))
+    expect = torch.where(done[:-1].unsqueeze(1).unsqueeze(1), torch.zeros_like(stone), planes[:-1] | stone)
+    assert torch.equal(planes[1:], expect)
+    del planes, occ, stone, expect, one
+    roll.run(640, record=False)  # a longer window so games cut off at its end do not bias the mean
+    episodes, black, white, draws, length = roll.stats.tolist()
+    assert episodes == black + white + draws and episodes > 900000
+    assert abs(length / episodes - 53.3) < 0.6
+    assert abs(draws / episodes - 0.0026) < 0.0012
+    assert black > white  # first-move advantage

@@ -1,0 +1,343 @@
+"""GPU parity: the HIP self-play wrapper, samplers, record unpack and GAE (through the C ABI)
+against the golden vectors of the reference and against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox
+from oracle.env_torch import OracleVectorEnv
+from oracle.packing import pack_boards, pack_cells, unpack_boards
+from oracle.policies import (FixedCellPolicy, HighestLegalPolicy, LowestLegalPolicy, MaskHashPolicy,
+                             PhiloxOpponent)
+from oracle.rollout import gae as oracle_gae
+from oracle.selfplay_torch import OracleSelfPlay
+from replay import golden_files, replay_selfplay_trace
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+OPP = {"lowest": LowestLegalPolicy, "highest": HighestLegalPolicy, "hash": MaskHashPolicy}
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import __graft_entry__ as entry
+
+    entry.build_hip()
+    entry._ensure_path()
+    import mnk_hip
+    from env.torch_vector_mnk_env import TorchVectorMnkEnv
+    from selfplay import policy, random_rollout, validation
+    from selfplay.torch_self_play_wrapper import TorchSelfPlayWrapper
+
+    mnk_hip.load()
+    assert torch.cuda.is_available()
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.lib, ns.Env, ns.Wrapper = mnk_hip, TorchVectorMnkEnv, TorchSelfPlayWrapper
+    ns.policy, ns.rollout, ns.validation = policy, random_rollout, validation
+    return ns
+
+
+# ----------------------------------------------------------------------------- G3 traces
+@pytest.mark.parametrize("idx", range(7))
+def test_selfplay_trace_matches_reference(hip, golden_dir, idx):
+    """TorchSelfPlayWrapper traces recorded from the reference (row-local deterministic opponents,
+    the sides the reference drew are replayed through force_sides)."""
+    path = golden_files(golden_dir, "selfplay_")[idx]
+    log = np.load(path)
+    m, n, k, nenv, _ = (int(v) for v in log["geom"])
+    wrap = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV))
+    wrap.set_opponent(OPP[path.split("_")[-2]]())
+    replay_selfplay_trace(wrap, log, lambda w, sides: w.force_sides(torch.from_numpy(sides.astype(np.int64))))
+
+
+# ----------------------------------------------------------------------------- the reference's own tests
+@pytest.fixture
+def wrapper_factory(hip):
+    """src/tests/test_mnk_integration.py:27-42"""
+
+    def _create(opponent_action_idx=0):
+        env = hip.Env(m=3, n=3, k=3, num_envs=1, device=DEV)
+        wrapper = hip.Wrapper(env)
+        wrapper.set_opponent(FixedCellPolicy(opponent_action_idx))
+        return wrapper
+
+    return _create
+
+
+def test_reference_canonical_view(wrapper_factory):
+    """src/tests/test_mnk_integration.py:89-114"""
+    wrapper = wrapper_factory()
+    wrapper.reset(options={"agent_side": 0})
+    wrapper.env.boards[0, 0, 0, 0] = 1.0
+    obs = wrapper.get_agent_obs()
+    assert obs["observation"][0, 0, 0, 0] == 1.0
+    wrapper.set_opponent(FixedCellPolicy(8))
+    wrapper.reset(options={"agent_side": 1})
+    wrapper.env.boards[0, 1, 0, 0] = 1.0
+    obs = wrapper.get_agent_obs()
+    assert obs["observation"][0, 0, 0, 0] == 1.0
+    assert obs["observation"][0, 1, 2, 2] == 1.0
+
+
+def test_reference_agent_win_reward(wrapper_factory):
+    """src/tests/test_mnk_integration.py:117-132"""
+    wrapper = wrapper_factory()
+    wrapper.reset(options={"agent_side": 0})
+    wrapper.env.boards[0, 0, 0, 0] = 1
+    wrapper.env.boards[0, 0, 0, 1] = 1
+    obs, rewards, terms, trunc, _ = wrapper.step(torch.tensor([2], device=wrapper.device))
+    assert rewards[0].item() == 1.0
+    assert terms[0].item() is True
+    assert obs["observation"][0, 0].sum() == 3.0
+
+
+def test_reference_opponent_win_penalty(wrapper_factory):
+    """src/tests/test_mnk_integration.py:135-161"""
+    wrapper = wrapper_factory(opponent_action_idx=5)
+    wrapper.reset(options={"agent_side": 0})
+    wrapper.env.boards[0, 0, 0, 0] = 1
+    wrapper.env.boards[0, 0, 0, 1] = 1
+    wrapper.env.boards[0, 1, 1, 0] = 1
+    wrapper.env.boards[0, 1, 1, 1] = 1
+    obs, rewards, terms, truncs, _ = wrapper.step(torch.tensor([6], device=wrapper.device))
+    assert terms[0].item() is True
+    assert rewards[0].item() == -1.0
+    assert obs["observation"][0, 1, 1, :].sum() == 3.0
+
+
+def test_reference_autoreset_next_step(wrapper_factory):
+    """src/tests/test_mnk_integration.py:164-189"""
+    wrapper = wrapper_factory()
+    wrapper.reset(options={"agent_side": 0})
+    wrapper.env.boards[0, 0, 0, 0] = 1
+    wrapper.env.boards[0, 0, 0, 1] = 1
+    obs, rewards, terms, _, _ = wrapper.step(torch.tensor([2], device=wrapper.device))
+    assert terms[0].item() is True
+    assert rewards[0].item() == 1.0
+    assert obs["observation"][0, 0].sum() == 3.0
+    wrapper.force_sides(0)
+    obs_new, rewards_new, terms_new, _, _ = wrapper.step(torch.tensor([0], device=wrapper.device))
+    assert terms_new[0].item() is False
+    assert rewards_new[0].item() == 0.0
+    assert obs_new["observation"][0, 0].sum() == 0.0
+
+
+def test_reference_opponent_starts_after_reset(wrapper_factory):
+    """src/tests/test_mnk_integration.py:192-207"""
+    wrapper = wrapper_factory(opponent_action_idx=4)
+    obs, _ = wrapper.reset(options={"agent_side": 1})
+    assert obs["observation"][0, 0].sum() == 0.0
+    assert obs["observation"][0, 1, 1, 1] == 1.0
+
+
+# ----------------------------------------------------------------------------- fused random-opponent step
+@pytest.mark.parametrize("m,n,k,nenv,steps", [(3, 3, 3, 200, 40), (9, 9, 5, 130, 150), (19, 19, 5, 64, 60),
+                                              (4, 6, 3, 65, 50)])
+def test_fused_random_opponent_step_matches_oracle(hip, m, n, k, nenv, steps):
+    """mnk_selfplay_step_random (one launch per agent-step) == OracleSelfPlay with the Philox
+    opponent and Philox sides; bit-exact state, obs, mask, rewards, terminated, sides."""
+    seed, id0 = 77, 4096
+    env = hip.Env(m, n, k, nenv, device=DEV)
+    wrap = hip.Wrapper(env, seed=seed)
+    wrap.env_id0 = id0
+    wrap.set_opponent(hip.policy.RandomPolicy(m * n))
+
+    ids = np.arange(id0, id0 + nenv, dtype=np.uint64)
+    state = {"step": 0, "resetting": None}
+
+    def sides(count):
+        x = philox.rand_u32(seed, ids, state["step"], philox.STREAM_SIDE)
+        s = torch.from_numpy(philox.draw_side(x))
+        return s if count == nenv else s[torch.nonzero(state["resetting"]).squeeze(1)]
+
+    ora = OracleSelfPlay(OracleVectorEnv(m, n, k, nenv), side_source=sides)
+    opp = PhiloxOpponent(seed, id0)
+    ora.set_opponent(opp)
+
+    def same(o_hip, o_ora, t):
+        assert torch.equal(o_hip["observation"].cpu(), o_ora["observation"]), f"obs {t}"
+        assert torch.equal(o_hip["action_mask"].cpu(), o_ora["action_mask"]), f"mask {t}"
+        assert torch.equal(wrap.agent_side.cpu(), ora.agent_side), f"sides {t}"
+        assert np.array_equal(pack_boards(env.boards.cpu().numpy(), m, n), pack_boards(ora.env.boards.numpy(), m, n))
+        assert torch.equal(env.current_player.cpu(), ora.env.current_player)
+        assert torch.equal(env.move_counts.cpu(), ora.env.move_counts)
+
+    o1, _ = wrap.reset()
+    o2, _ = ora.reset()
+    same(o1, o2, "reset")
+    rng = np.random.default_rng(0)
+    for t in range(steps):
+        state["step"] = opp.step = t + 1
+        state["resetting"] = ora.pending_resets.clone()
+        mask = o2["action_mask"].numpy()
+        acts = np.array([rng.choice(np.nonzero(row)[0]) for row in mask], dtype=np.int64)
+        o1, r1, t1, tr1, _ = wrap.step(torch.from_numpy(acts).to(DEV))
+        o2, r2, t2, tr2, _ = ora.step(torch.from_numpy(acts))
+        assert torch.equal(r1.cpu(), r2) and torch.equal(t1.cpu(), t2), f"rewards / terminated {t}"
+        assert torch.equal(wrap.pending_resets.cpu(), ora.pending_resets)
+        same(o1, o2, t)
+
+
+def test_two_launch_path_equals_fused_path(hip):
+    """pre + policy + post with a policy that reproduces the Philox picks == the one-launch path."""
+    m, n, k, nenv, seed = 9, 9, 5, 257, 5
+    a_env, b_env = hip.Env(m, n, k, nenv, device=DEV), hip.Env(m, n, k, nenv, device=DEV)
+    fused, split = hip.Wrapper(a_env, seed=seed), hip.Wrapper(b_env, seed=seed)
+    fused.set_opponent(hip.policy.RandomPolicy(m * n))
+
+    class SamePicks:
+        def act(self, obs):
+            acts = torch.empty(nenv, dtype=torch.long, device=DEV)
+            b_env.sample_legal_into(acts, seed=seed, step=split.step_count - 1, env_id0=0,
+                                    stream_id=hip.lib.STREAM_OPP)
+            return acts
+
+    split.set_opponent(SamePicks())
+    o1, _ = fused.reset()
+    o2, _ = split.reset()
+    rng = torch.Generator(device="cpu").manual_seed(0)
+    for t in range(120):
+        assert torch.equal(o1["observation"], o2["observation"]) and torch.equal(o1["action_mask"], o2["action_mask"])
+        acts = torch.multinomial(o1["action_mask"].float().cpu(), 1, generator=rng).squeeze(1).to(DEV)
+        o1, r1, t1, _, _ = fused.step(acts)
+        o2, r2, t2, _, _ = split.step(acts)
+        assert torch.equal(r1, r2) and torch.equal(t1, t2)
+        assert torch.equal(fused.agent_side, split.agent_side)
+    assert set(r1.unique().tolist()) <= {-1.0, 0.0, 1.0}
+
+
+# ----------------------------------------------------------------------------- masked-logits sampler
+def test_masked_logits_head_matches_reference(hip, golden_dir):
+    """G6 (epilogue): raw logits + mask -> argmax and log-prob of the reference's masked Categorical
+    (cnn.py:69-79).  Tolerance 1e-5 on log-probabilities (f32 logsumexp, different summation order)."""
+    g = np.load(f"{golden_dir}/masked_logits.npz")
+    sampler = hip.policy._HipSampler(seed=1)
+    for arch in ("cnn_b_s", "resnet_b_s"):
+        raw = torch.from_numpy(g[arch + "_raw_logits"]).to(DEV)
+        mask = torch.from_numpy(g[arch + "_mask"]).to(DEV)
+        want = g[arch + "_masked_logits"]
+        act, logp = sampler.draw(raw, mask, deterministic=True, want_logp=True)
+        act, logp = act.cpu().numpy(), logp.cpu().numpy()
+        assert np.array_equal(act, want.argmax(axis=1))
+        assert np.allclose(logp, want[np.arange(len(act)), act], atol=1e-5, rtol=0)
+        # sampled actions are always legal (or anything on the all-masked row), with the right log-prob
+        act, logp = sampler.draw(raw, mask, deterministic=False, want_logp=True)
+        act, logp = act.cpu().numpy(), logp.cpu().numpy()
+        rows = np.nonzero(g[arch + "_mask"].any(axis=1))[0]
+        assert g[arch + "_mask"][rows, act[rows]].all()
+        assert np.allclose(logp, want[np.arange(len(act)), act], atol=1e-5, rtol=0)
+
+
+def test_sampler_distribution_chi_square(hip, golden_dir):
+    """Distributional parity of the Gumbel-max draw with the reference's probabilities:
+    chi-square over 200 000 draws of one row, threshold = 99.9 % quantile."""
+    from scipy.stats import chi2
+
+    g = np.load(f"{golden_dir}/masked_logits.npz")
+    row = 20
+    raw = torch.from_numpy(g["cnn_b_s_raw_logits"][row]).to(DEV)
+    mask = torch.from_numpy(g["cnn_b_s_mask"][row]).to(DEV)
+    probs = g["cnn_b_s_probs"][row].astype(np.float64)
+    draws = 200000
+    sampler = hip.policy._HipSampler(seed=9)
+    # independent draws of the same row: Philox is keyed by the row's env id
+    acts = sampler.draw(raw.expand(draws, -1), mask.expand(draws, -1), deterministic=False).cpu().numpy()
+    counts = np.bincount(acts, minlength=len(probs)).astype(np.float64)
+    assert counts[probs == 0].sum() == 0
+    keep = probs > 0
+    stat = (((counts - draws * probs) ** 2)[keep] / (draws * probs[keep])).sum()
+    assert stat < chi2.ppf(0.999, keep.sum() - 1)
+
+
+def test_random_policy_is_uniform_over_legal(hip):
+    pol = hip.policy.RandomPolicy(9, seed=3)
+    mask = torch.zeros((90000, 9), dtype=torch.bool, device=DEV)
+    mask[:, [0, 4, 5]] = True
+    acts = pol.act({"action_mask": mask}).cpu().numpy()
+    counts = np.bincount(acts, minlength=9)
+    assert counts[[0, 4, 5]].sum() == 90000 and np.all(np.abs(counts[[0, 4, 5]] - 30000) < 700)
+    assert pol.act({"action_mask": mask}, deterministic=True).unique().tolist() == [0]
+    empty = torch.zeros((4000, 9), dtype=torch.bool, device=DEV)
+    acts = pol.act({"action_mask": empty}).cpu().numpy()  # policy.py:21-24: uniform over all cells
+    assert set(acts.tolist()) == set(range(9))
+
+
+# ----------------------------------------------------------------------------- records and GAE
+@pytest.mark.parametrize("m,n,k,nenv,steps", [(3, 3, 3, 70, 12), (9, 9, 5, 200, 30), (19, 19, 5, 33, 20)])
+def test_unpack_records_matches_numpy(hip, m, n, k, nenv, steps):
+    env = hip.Env(m, n, k, nenv, device=DEV)
+    rec = hip.rollout.RandomRollout(env, seed=2).run(steps)
+    buf = hip.rollout.unpack_records(rec, env)
+    planes = rec.planes.cpu().numpy().view(np.uint64)
+    meta = rec.meta.cpu().numpy().view(np.uint32)
+    side = (meta >> 25) & 1
+    for t in range(steps):
+        dense = unpack_boards(planes[t], m, n)
+        flip = side[t] == 1
+        dense[flip] = dense[flip][:, ::-1]
+        assert np.array_equal(buf["observations"][t].cpu().numpy(), dense)
+        legal = ~(dense != 0).any(axis=1).reshape(nenv, m * n)
+        assert np.array_equal(buf["action_masks"][t].cpu().numpy(), legal)
+    assert np.array_equal(buf["actions"].cpu().numpy(), (meta & 0xFFFF).astype(np.int64))
+    assert np.array_equal(buf["rewards"].cpu().numpy(), ((meta >> 16) & 0xFF).astype(np.int8).astype(np.float32))
+    assert np.array_equal(buf["dones"].cpu().numpy(), ((meta >> 24) & 1).astype(bool))
+
+
+def test_gae_matches_reference_arithmetic(hip):
+    """mnk_gae == rollout_buffer.py:60-80 restated in f32 numpy, bit for bit."""
+    rng = np.random.default_rng(0)
+    t, n = 64, 1000
+    rewards = rng.choice([-1.0, 0.0, 1.0], size=(t, n)).astype(np.float32)
+    values = rng.standard_normal((t, n)).astype(np.float32)
+    dones = rng.random((t, n)) < 0.05
+    last = rng.standard_normal(n).astype(np.float32)
+    adv, ret = hip.rollout.gae(torch.from_numpy(rewards).to(DEV), torch.from_numpy(values).to(DEV),
+                               torch.from_numpy(dones).to(DEV), torch.from_numpy(last).to(DEV), 0.99, 0.95)
+    want_adv, want_ret = oracle_gae(rewards, values, dones, last, 0.99, 0.95)
+    assert np.array_equal(adv.cpu().numpy(), want_adv)
+    assert np.array_equal(ret.cpu().numpy(), want_ret)
+
+
+# ----------------------------------------------------------------------------- callers
+def test_validate_gpu_runs_and_counts(hip):
+    """selfplay/validation.py:6-44 on the HIP wrapper: random vs random on 3x3x3."""
+    res = hip.validation.validate_gpu(hip.policy.RandomPolicy(9, seed=1), hip.policy.RandomPolicy(9, seed=2),
+                                      (3, 3, 3), n_episodes=4096, device=DEV)
+    w, l, d = (res[f"validation/vs_benchmark/{k}_rate"] for k in ("win", "loss", "draw"))
+    assert abs(w + l + d - 1.0) < 1e-9 and res["validation/vs_benchmark/games_played"] == 4096
+    assert abs(d - 0.127) < 0.03  # 12.65 % draws under uniform random play
+    assert 0.3 < w < 0.6 and 0.3 < l < 0.6
+
+
+def test_ppo_rollout_call_pattern(hip):
+    """The call sequence of alg/ppo.py:81-124 -- reset once, then net(obs, mask) -> sample -> step ->
+    keep obs for the next iteration -- runs on the HIP wrapper with a torch network in the loop."""
+    m, n, k, nenv = 9, 9, 5, 512
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(2 * m * n, m * n)).to(DEV)
+    wrap = hip.Wrapper(hip.Env(m, n, k, nenv, device="cuda"))
+    wrap.set_opponent(hip.policy.RandomPolicy(m * n))
+    obs, _ = wrap.reset()
+    ep_reward = torch.zeros(nenv, device=DEV)
+    finished = 0
+    for _ in range(100):
+        observation, action_mask = obs["observation"], obs["action_mask"]
+        assert observation.shape == (nenv, 2, m, n) and action_mask.shape == (nenv, m * n)
+        assert bool(action_mask.any(dim=1).all())  # Categorical stays valid (wrapper:108-110)
+        with torch.no_grad():
+            logits = torch.where(action_mask, net(observation), torch.tensor(-torch.inf, device=DEV))
+            dist = torch.distributions.Categorical(logits=logits)
+            actions = dist.sample()
+        next_obs, rewards, terminateds, truncateds, _ = wrap.step(actions)
+        dones = terminateds | truncateds
+        ep_reward += rewards
+        finished += int(dones.sum())
+        # the observation handed out at t is still intact after the step (ppo.py:106 stores it afterwards)
+        assert torch.equal(observation, obs["observation"])
+        obs = next_obs
+    assert finished > nenv  # games end and restart
+    assert set(rewards.unique().tolist()) <= {-1.0, 0.0, 1.0}
