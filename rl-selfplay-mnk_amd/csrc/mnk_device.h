@@ -1,92 +1,104 @@
 // mnk_device.h -- device-side building blocks shared by the MNK kernels (gfx950 only).
 //
-// One lane owns one env.  A board plane is WT u64 words in registers (guard-column
-// layout, see include/mnk_hip.h); the K-in-a-row test of the reference
-// (env/torch_vector_mnk_env.py:106-119: three conv2d's with ones / eye stencils over
-// the mover's whole plane, "> k - 0.1") becomes four shift-AND chains on that bit
-// string -- shifts 1 (row), n+1 (column), n+2 (diagonal), n (anti-diagonal) -- which
-// is exact integer arithmetic, so it reproduces the f32 sums of 0/1 values bit for bit.
+// One lane owns one env.  A board plane is a bit string in the guard-column layout of
+// include/mnk_hip.h, held in registers as NW 32-bit words (9x9: 90 bits = 3 VGPRs per
+// plane; in memory it stays u64[W], the unused top half-word is simply never loaded).
+// The K-in-a-row test of the reference (env/torch_vector_mnk_env.py:106-119: three
+// conv2d's with ones / eye stencils over the mover's whole plane, "> k - 0.1") becomes
+// four shift-AND chains on that bit string -- shifts 1 (row), n+1 (column), n+2
+// (diagonal), n (anti-diagonal) -- exact integer arithmetic, so it reproduces the f32
+// sums of 0/1 values bit for bit.  Multi-word shifts are v_alignbit_b32 per word.
+//
+// Templates: NW = register words per plane; CN / CK = board width / run length when
+// they are compile-time constants (0 = read them from MnkGeom at run time).  The
+// specialised forms turn every shift amount into an immediate and unroll the run
+// doubling; the generic forms keep wave-uniform loops.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define MNK_MAX_W 8
+#define MNK_MAX_W 8     // u64 words per plane in memory
+#define MNK_MAX_NW 16   // u32 words per plane in registers
 
 struct MnkGeom {
   int m, n, k;
   int C;        // m*n cells = number of actions
   int W;        // u64 words per plane in memory
+  int NW;       // u32 words that actually hold board bits: ceil(m*(n+1)/32)
   int stride;   // n+1 bits per board row (guard column included)
   uint32_t magic_n;       // x / n      == __umulhi(x, magic_n)      for x*n      < 2^32
   uint32_t magic_stride;  // x / (n+1)
   uint32_t magic_C;       // x / C
   uint32_t magic_2C;      // x / (2C)
-  uint64_t valid[MNK_MAX_W];  // 1 on real cells, 0 on guard / padding bits
+  uint32_t valid[MNK_MAX_NW];  // 1 on real cells, 0 on guard / padding bits
 };
 
 __device__ __forceinline__ uint32_t mnk_div(uint32_t x, uint32_t magic) { return __umulhi(x, magic); }
 
+template <int CN>
+__device__ __forceinline__ int geom_n(const MnkGeom& g) { return CN ? CN : g.n; }
+template <int CK>
+__device__ __forceinline__ int geom_k(const MnkGeom& g) { return CK ? CK : g.k; }
+
 // ---------------------------------------------------------------- multi-word bit strings
-template <int WT>
-__device__ __forceinline__ void bs_shr(uint64_t (&x)[WT], int s) {
-  // s is wave-uniform (depends on the geometry only)
-  while (s > 63) {
+// x >>= s for a wave-uniform s >= 0 (an immediate in the specialised kernels)
+template <int NW>
+__device__ __forceinline__ void bs_shr(uint32_t (&x)[NW], int s) {
+  for (int q = s >> 5; q > 0; --q) {
 #pragma unroll
-    for (int w = 0; w < WT; ++w) x[w] = (x[w] >> 63) | (w + 1 < WT ? (x[w + 1] << 1) : 0ull);
-    s -= 63;
+    for (int w = 0; w < NW; ++w) x[w] = (w + 1 < NW) ? x[w + 1] : 0u;
   }
-  if (s == 0) return;
+  const int r = s & 31;
+  if (r) {
 #pragma unroll
-  for (int w = 0; w < WT; ++w) x[w] = (x[w] >> s) | (w + 1 < WT ? (x[w + 1] << (64 - s)) : 0ull);
+    for (int w = 0; w < NW; ++w) x[w] = __builtin_amdgcn_alignbit((w + 1 < NW) ? x[w + 1] : 0u, x[w], (uint32_t)r);
+  }
 }
 
-// does the bit string hold a run of >= k set bits spaced d apart?
-template <int WT>
-__device__ __forceinline__ bool bs_has_run(const uint64_t (&b)[WT], int d, int k) {
-  uint64_t x[WT], t[WT];
+// does the bit string hold k set bits spaced d apart?  log2(k) doubling steps.
+template <int NW>
+__device__ __forceinline__ bool bs_has_run(const uint32_t (&b)[NW], int d, int k) {
+  uint32_t x[NW], t[NW];
 #pragma unroll
-  for (int w = 0; w < WT; ++w) x[w] = b[w];
+  for (int w = 0; w < NW; ++w) x[w] = b[w];
   int len = 1;  // x marks the starts of runs of >= len
   while (2 * len <= k) {
 #pragma unroll
-    for (int w = 0; w < WT; ++w) t[w] = x[w];
-    bs_shr<WT>(t, len * d);
+    for (int w = 0; w < NW; ++w) t[w] = x[w];
+    bs_shr<NW>(t, len * d);
 #pragma unroll
-    for (int w = 0; w < WT; ++w) x[w] &= t[w];
+    for (int w = 0; w < NW; ++w) x[w] &= t[w];
     len *= 2;
   }
   if (len < k) {
 #pragma unroll
-    for (int w = 0; w < WT; ++w) t[w] = x[w];
-    bs_shr<WT>(t, (k - len) * d);
+    for (int w = 0; w < NW; ++w) t[w] = x[w];
+    bs_shr<NW>(t, (k - len) * d);
 #pragma unroll
-    for (int w = 0; w < WT; ++w) x[w] &= t[w];
+    for (int w = 0; w < NW; ++w) x[w] &= t[w];
   }
-  uint64_t any = 0;
+  uint32_t any = 0;
 #pragma unroll
-  for (int w = 0; w < WT; ++w) any |= x[w];
+  for (int w = 0; w < NW; ++w) any |= x[w];
   return any != 0;
 }
 
 // env/torch_vector_mnk_env.py:106-119 on one plane
-template <int WT>
-__device__ __forceinline__ bool mnk_plane_wins(const MnkGeom& g, const uint64_t (&b)[WT]) {
-  bool hit = bs_has_run<WT>(b, 1, g.k);
-  hit |= bs_has_run<WT>(b, g.stride, g.k);
-  hit |= bs_has_run<WT>(b, g.stride + 1, g.k);
-  hit |= bs_has_run<WT>(b, g.n, g.k);
+template <int NW, int CN, int CK>
+__device__ __forceinline__ bool mnk_plane_wins(const MnkGeom& g, const uint32_t (&b)[NW]) {
+  const int n = geom_n<CN>(g), k = geom_k<CK>(g);
+  bool hit = bs_has_run<NW>(b, 1, k);      // rows
+  hit |= bs_has_run<NW>(b, n + 1, k);      // columns
+  hit |= bs_has_run<NW>(b, n + 2, k);      // diagonals
+  hit |= bs_has_run<NW>(b, n, k);          // anti-diagonals
   return hit;
 }
 
 // position of the r-th (0-based) set bit of v; r < popcount(v)
-__device__ __forceinline__ int select_bit64(uint64_t v, int r) {
-  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-  int c = __popc(lo);
+__device__ __forceinline__ int select_bit32(uint32_t x, int r) {
   int pos = 0;
-  uint32_t x = lo;
-  if (r >= c) { r -= c; x = hi; pos = 32; }
-  c = __popc(x & 0xFFFFu);
-  if (r >= c) { r -= c; x >>= 16; pos += 16; }
+  int c = __popc(x & 0xFFFFu);
+  if (r >= c) { r -= c; x >>= 16; pos = 16; }
   c = __popc(x & 0xFFu);
   if (r >= c) { r -= c; x >>= 8; pos += 8; }
   c = __popc(x & 0xFu);
@@ -97,28 +109,28 @@ __device__ __forceinline__ int select_bit64(uint64_t v, int r) {
   return pos;
 }
 
-template <int WT>
-__device__ __forceinline__ int bs_popcount(const uint64_t (&x)[WT]) {
+template <int NW>
+__device__ __forceinline__ int bs_popcount(const uint32_t (&x)[NW]) {
   int c = 0;
 #pragma unroll
-  for (int w = 0; w < WT; ++w) c += __popcll(x[w]);
+  for (int w = 0; w < NW; ++w) c += __popc(x[w]);
   return c;
 }
 
 // bit index of the r-th set bit of the multi-word string; r < popcount
-template <int WT>
-__device__ __forceinline__ int bs_select(const uint64_t (&x)[WT], int r) {
-  uint64_t word = x[0];
+template <int NW>
+__device__ __forceinline__ int bs_select(const uint32_t (&x)[NW], int r) {
+  uint32_t word = x[0];
   int base = 0;
   bool found = false;
 #pragma unroll
-  for (int w = 0; w < WT; ++w) {
-    int c = __popcll(x[w]);
-    bool here = !found && r < c;
-    if (here) { word = x[w]; base = 64 * w; found = true; }
+  for (int w = 0; w < NW; ++w) {
+    const int c = __popc(x[w]);
+    const bool here = !found && r < c;
+    if (here) { word = x[w]; base = 32 * w; found = true; }
     if (!found) r -= c;
   }
-  return base + select_bit64(word, r);
+  return base + select_bit32(word, r);
 }
 
 // ---------------------------------------------------------------- Philox4x32-10
@@ -160,58 +172,73 @@ __device__ __forceinline__ uint32_t mnk_rand_u32(uint64_t seed, uint64_t env, ui
 }
 
 // ---------------------------------------------------------------- one env in registers
-template <int WT>
+template <int NW>
 struct MnkEnv {
-  uint64_t p[2][WT];
+  uint32_t p[2][NW];
   uint32_t meta;  // bit0 side to move, bits 1.. move count
 };
 
-template <int WT>
-__device__ __forceinline__ void env_load(MnkEnv<WT>& e, const uint64_t* planes, const uint32_t* meta, int64_t N,
+// planes u64[2][W][N] in memory <-> NW u32 words per plane in registers
+template <int NW>
+__device__ __forceinline__ void plane_load(uint32_t (&x)[NW], const uint64_t* plane, int64_t N, int W, int64_t i) {
+#pragma unroll
+  for (int q = 0; q < (NW + 1) / 2; ++q) {
+    const uint64_t v = (q < W) ? plane[(int64_t)q * N + i] : 0ull;
+    x[2 * q] = (uint32_t)v;
+    if (2 * q + 1 < NW) x[2 * q + 1] = (uint32_t)(v >> 32);
+  }
+}
+
+template <int NW>
+__device__ __forceinline__ void plane_store(const uint32_t (&x)[NW], uint64_t* plane, int64_t N, int W, int64_t i) {
+#pragma unroll
+  for (int q = 0; q < (NW + 1) / 2; ++q) {
+    const uint64_t hi = (2 * q + 1 < NW) ? (uint64_t)x[2 * q + 1] : 0ull;
+    if (q < W) plane[(int64_t)q * N + i] = (uint64_t)x[2 * q] | (hi << 32);
+  }
+}
+
+template <int NW>
+__device__ __forceinline__ void env_load(MnkEnv<NW>& e, const uint64_t* planes, const uint32_t* meta, int64_t N,
                                          int W, int64_t i) {
-#pragma unroll
-  for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-    for (int w = 0; w < WT; ++w) e.p[pl][w] = (w < W) ? planes[((int64_t)(pl * W + w)) * N + i] : 0ull;
+  plane_load<NW>(e.p[0], planes, N, W, i);
+  plane_load<NW>(e.p[1], planes + (int64_t)W * N, N, W, i);
   e.meta = meta[i];
 }
 
-template <int WT>
-__device__ __forceinline__ void env_store(const MnkEnv<WT>& e, uint64_t* planes, uint32_t* meta, int64_t N, int W,
+template <int NW>
+__device__ __forceinline__ void env_store(const MnkEnv<NW>& e, uint64_t* planes, uint32_t* meta, int64_t N, int W,
                                           int64_t i) {
-#pragma unroll
-  for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-    for (int w = 0; w < WT; ++w)
-      if (w < W) planes[((int64_t)(pl * W + w)) * N + i] = e.p[pl][w];
+  plane_store<NW>(e.p[0], planes, N, W, i);
+  plane_store<NW>(e.p[1], planes + (int64_t)W * N, N, W, i);
   meta[i] = e.meta;
 }
 
-template <int WT>
-__device__ __forceinline__ void env_clear(MnkEnv<WT>& e) {
+template <int NW>
+__device__ __forceinline__ void env_clear(MnkEnv<NW>& e) {
 #pragma unroll
   for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-    for (int w = 0; w < WT; ++w) e.p[pl][w] = 0ull;
+    for (int w = 0; w < NW; ++w) e.p[pl][w] = 0u;
   e.meta = 0u;
 }
 
-template <int WT>
-__device__ __forceinline__ void env_legal(const MnkGeom& g, const MnkEnv<WT>& e, uint64_t (&legal)[WT]) {
+template <int NW>
+__device__ __forceinline__ void env_legal(const MnkGeom& g, const MnkEnv<NW>& e, uint32_t (&legal)[NW]) {
 #pragma unroll
-  for (int w = 0; w < WT; ++w) legal[w] = ~(e.p[0][w] | e.p[1][w]) & g.valid[w];
+  for (int w = 0; w < NW; ++w) legal[w] = ~(e.p[0][w] | e.p[1][w]) & g.valid[w];
 }
 
 // uniform legal cell from one u32 (oracle/philox.py pick_legal; selfplay/policy.py:18-29)
-template <int WT>
-__device__ __forceinline__ int env_pick_legal(const MnkGeom& g, const MnkEnv<WT>& e, uint32_t x) {
-  uint64_t legal[WT];
-  env_legal<WT>(g, e, legal);
-  int nl = bs_popcount<WT>(legal);
+template <int NW, int CN>
+__device__ __forceinline__ int env_pick_legal(const MnkGeom& g, const MnkEnv<NW>& e, uint32_t x) {
+  uint32_t legal[NW];
+  env_legal<NW>(g, e, legal);
+  const int nl = bs_popcount<NW>(legal);
   if (nl == 0) return (int)__umulhi(x, (uint32_t)g.C);
-  int r = (int)__umulhi(x, (uint32_t)nl);
-  int bit = bs_select<WT>(legal, r);
-  return bit - (int)mnk_div((uint32_t)bit, g.magic_stride);
+  const int r = (int)__umulhi(x, (uint32_t)nl);
+  const uint32_t bit = (uint32_t)bs_select<NW>(legal, r);
+  return (int)(bit - (CN ? bit / (uint32_t)(CN + 1) : mnk_div(bit, g.magic_stride)));
 }
 
 struct MnkPly {
@@ -220,37 +247,37 @@ struct MnkPly {
 };
 
 // env/torch_vector_mnk_env.py:60-84 for one env.
-template <int WT>
-__device__ __forceinline__ MnkPly env_play(const MnkGeom& g, MnkEnv<WT>& e, int64_t action, bool strict) {
+template <int NW, int CN, int CK>
+__device__ __forceinline__ MnkPly env_play(const MnkGeom& g, MnkEnv<NW>& e, int64_t action, bool strict) {
   MnkPly out;
   out.win = false; out.done = false; out.err = 0;
   const int C = g.C;
-  int64_t a64 = action < 0 ? action + C : action;  // torch indexing wraps negatives (:68)
+  const int64_t a64 = action < 0 ? action + C : action;  // torch indexing wraps negatives (:68)
   if (a64 < 0 || a64 >= C) { out.err = 1; return out; }
   const uint32_t a = (uint32_t)a64;
-  const uint32_t bit = a + mnk_div(a, g.magic_n);  // row*(n+1) + col
-  const int wsel = (int)(bit >> 6);
-  const uint64_t one = 1ull << (bit & 63u);
+  const uint32_t bit = a + (CN ? a / (uint32_t)CN : mnk_div(a, g.magic_n));  // row*(n+1) + col
+  const int wsel = (int)(bit >> 5);
+  const uint32_t one = 1u << (bit & 31u);
   const uint32_t side = e.meta & 1u;
   if (strict) {
-    uint64_t occ = 0;
+    uint32_t occ = 0;
 #pragma unroll
-    for (int w = 0; w < WT; ++w) occ |= (w == wsel) ? ((e.p[0][w] | e.p[1][w]) & one) : 0ull;
+    for (int w = 0; w < NW; ++w) occ |= (w == wsel) ? ((e.p[0][w] | e.p[1][w]) & one) : 0u;
     if (occ) { out.err = 2; return out; }
   }
-  uint64_t mine[WT];
+  uint32_t mine[NW];
 #pragma unroll
-  for (int w = 0; w < WT; ++w) {
-    const uint64_t add = (w == wsel) ? one : 0ull;
-    e.p[0][w] |= side ? 0ull : add;   // :68 boards[idx, player, r, c] = 1
-    e.p[1][w] |= side ? add : 0ull;
+  for (int w = 0; w < NW; ++w) {
+    const uint32_t add = (w == wsel) ? one : 0u;
+    e.p[0][w] |= side ? 0u : add;   // :68 boards[idx, player, r, c] = 1
+    e.p[1][w] |= side ? add : 0u;
     mine[w] = side ? e.p[1][w] : e.p[0][w];
   }
-  const uint32_t moves = (e.meta >> 1) + 1u;           // :69
-  out.win = mnk_plane_wins<WT>(g, mine);                // :71
-  const bool draw = (moves >= (uint32_t)C) && !out.win;  // :72
-  out.done = out.win || draw;                           // :73
-  e.meta = (moves << 1) | (side ^ 1u);                  // :82 toggles even when finished
+  const uint32_t moves = (e.meta >> 1) + 1u;                 // :69
+  out.win = mnk_plane_wins<NW, CN, CK>(g, mine);              // :71
+  const bool draw = (moves >= (uint32_t)C) && !out.win;       // :72
+  out.done = out.win || draw;                                 // :73
+  e.meta = (moves << 1) | (side ^ 1u);                        // :82 toggles even when finished
   return out;
 }
 

@@ -4,30 +4,31 @@
 // consumers want dense row-major tensors: observation f32[N][2][m][n] (648 B/env at
 // 9x9) and action_mask bool[N][m*n] (env/torch_vector_mnk_env.py:46-53).  Written by
 // the env's own lane those would be 64 lanes x 648-byte stride -- uncoalesced.  So a
-// workgroup parks the packed planes of its B envs in LDS (3*W words per env: channel
-// 0, channel 1, legal cells), and then all its lanes sweep the workgroup's contiguous
+// workgroup parks the packed planes of its B envs in LDS (3*NW 32-bit words per env:
+// channel 0, channel 1, legal cells), and then all its lanes sweep the workgroup's contiguous
 // output slab in 16-byte vectors, each lane expanding the bits it needs from LDS.
 // HBM sees only full-width coalesced stores; the slab of workgroup b is the byte range
 // [b*B*rowbytes, (b+1)*B*rowbytes).
 #pragma once
 #include "mnk_device.h"
 
-// LDS image: u64 stage[3*W][B] followed by u32 tab_obs[2C] and u32 tab_mask[C].
-// A table entry = (u32 index of the word for env 0) << 5 | bit-in-word.
+// LDS image: u32 stage[3*NW][B] followed by u32 tab_obs[2C] and u32 tab_mask[C].
+// A table entry = (index of the word for env 0) << 5 | bit-in-word; lanes that expand
+// neighbouring cells read the same or adjacent words: broadcast or conflict-free.
 struct MnkStage {
-  uint64_t* words;    // [3*W][B]
+  uint32_t* words;    // [3*NW][B]
   uint32_t* tab_obs;  // [2C]
   uint32_t* tab_mask; // [C]
 };
 
-__host__ __device__ inline size_t mnk_stage_bytes(int W, int C, int B) {
-  return (size_t)3 * W * B * 8 + (size_t)3 * C * 4;
+__host__ __device__ inline size_t mnk_stage_bytes(int NW, int C, int B) {
+  return (size_t)3 * NW * B * 4 + (size_t)3 * C * 4;
 }
 
 __device__ __forceinline__ MnkStage mnk_stage_carve(void* lds, const MnkGeom& g, int B) {
   MnkStage s;
-  s.words = (uint64_t*)lds;
-  s.tab_obs = (uint32_t*)(s.words + (size_t)3 * g.W * B);
+  s.words = (uint32_t*)lds;
+  s.tab_obs = s.words + (size_t)3 * g.NW * B;
   s.tab_mask = s.tab_obs + 2 * g.C;
   return s;
 }
@@ -37,43 +38,43 @@ __device__ __forceinline__ void mnk_stage_tables(const MnkStage& s, const MnkGeo
     const int plane = r >= 2 * g.C ? 2 : (r >= g.C ? 1 : 0);
     const uint32_t cell = (uint32_t)(r - plane * g.C);
     const uint32_t bit = cell + mnk_div(cell, g.magic_n);
-    const uint32_t wq = (uint32_t)(plane * g.W) + (bit >> 6);
-    const uint32_t entry = ((wq * 2u * (uint32_t)B + ((bit >> 5) & 1u)) << 5) | (bit & 31u);
+    const uint32_t wq = (uint32_t)(plane * g.NW) + (bit >> 5);
+    const uint32_t entry = ((wq * (uint32_t)B) << 5) | (bit & 31u);
     s.tab_obs[r] = entry;  // tab_mask aliases tab_obs + 2C
   }
 }
 
 // one env's planes into the stage; ch0/ch1 already in the order the viewer wants
-template <int WT>
+template <int NW>
 __device__ __forceinline__ void mnk_stage_put(const MnkStage& s, const MnkGeom& g, int B, int el,
-                                              const uint64_t (&ch0)[WT], const uint64_t (&ch1)[WT],
+                                              const uint32_t (&ch0)[NW], const uint32_t (&ch1)[NW],
                                               bool fix_empty) {
-  uint64_t any = 0;
-  uint64_t legal[WT];
+  uint32_t any = 0;
+  uint32_t legal[NW];
 #pragma unroll
-  for (int w = 0; w < WT; ++w) {
+  for (int w = 0; w < NW; ++w) {
     legal[w] = ~(ch0[w] | ch1[w]) & g.valid[w];
     any |= legal[w];
   }
-  if (fix_empty && any == 0) legal[0] = 1ull;  // wrapper:108-110  mask[invalid, 0] = True
+  if (fix_empty && any == 0) legal[0] = 1u;  // wrapper:108-110  mask[invalid, 0] = True
 #pragma unroll
-  for (int w = 0; w < WT; ++w) {
-    if (w < g.W) {
-      s.words[(size_t)(0 * g.W + w) * B + el] = ch0[w];
-      s.words[(size_t)(1 * g.W + w) * B + el] = ch1[w];
-      s.words[(size_t)(2 * g.W + w) * B + el] = legal[w];
+  for (int w = 0; w < NW; ++w) {
+    if (w < g.NW) {
+      s.words[(0 * g.NW + w) * B + el] = ch0[w];
+      s.words[(1 * g.NW + w) * B + el] = ch1[w];
+      s.words[(2 * g.NW + w) * B + el] = legal[w];
     }
   }
 }
 
 __device__ __forceinline__ uint32_t mnk_stage_bit(const uint32_t* st32, uint32_t entry, uint32_t el) {
-  return (st32[(entry >> 5) + 2u * el] >> (entry & 31u)) & 1u;
+  return (st32[(entry >> 5) + el] >> (entry & 31u)) & 1u;
 }
 
 // obs slab of this workgroup: nb envs x 2C floats starting at dst (16-byte aligned when vec)
 __device__ __forceinline__ void mnk_emit_obs(const MnkStage& s, const MnkGeom& g, int nb, float* dst, bool vec,
                                              int tid, int nthreads) {
-  const uint32_t* st32 = (const uint32_t*)s.words;
+  const uint32_t* st32 = s.words;
   const uint32_t row = 2u * (uint32_t)g.C;
   const uint32_t total = (uint32_t)nb * row;
   const uint32_t nvec = vec ? (total >> 2) : 0u;
@@ -99,7 +100,7 @@ __device__ __forceinline__ void mnk_emit_obs(const MnkStage& s, const MnkGeom& g
 // mask slab: nb envs x C bytes starting at dst
 __device__ __forceinline__ void mnk_emit_mask(const MnkStage& s, const MnkGeom& g, int nb, uint8_t* dst, bool vec,
                                               int tid, int nthreads) {
-  const uint32_t* st32 = (const uint32_t*)s.words;
+  const uint32_t* st32 = s.words;
   const uint32_t row = (uint32_t)g.C;
   const uint32_t total = (uint32_t)nb * row;
   const uint32_t nvec = vec ? (total >> 4) : 0u;

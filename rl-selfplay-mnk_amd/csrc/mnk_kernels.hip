@@ -26,7 +26,7 @@ static int mnk_make_geom(int m, int n, int k, MnkGeom* g) {
   if (W > MNK_MAX_W) return MNK_EGEOM;
   memset(g, 0, sizeof(*g));
   g->m = m; g->n = n; g->k = k;
-  g->C = m * n; g->W = W; g->stride = n + 1;
+  g->C = m * n; g->W = W; g->NW = (bits + 31) / 32; g->stride = n + 1;
   auto magic = [](uint32_t d) { return (uint32_t)((1ull << 32) / d + 1ull); };
   g->magic_n = n == 1 ? 0u : magic((uint32_t)n);  // n == 1: x / 1 handled below
   g->magic_stride = magic((uint32_t)(n + 1));
@@ -35,7 +35,7 @@ static int mnk_make_geom(int m, int n, int k, MnkGeom* g) {
   for (int r = 0; r < m; ++r)
     for (int c = 0; c < n; ++c) {
       const int b = r * (n + 1) + c;
-      g->valid[b >> 6] |= 1ull << (b & 63);
+      g->valid[b >> 5] |= 1u << (b & 31);
     }
   return MNK_OK;
 }
@@ -64,18 +64,27 @@ static int mnk_block_envs(int64_t N) {
   return 64;
 }
 
-#define MNK_DISPATCH_W(W, CALL)                      \
-  do {                                               \
-    switch (W) {                                     \
-      case 1: { constexpr int WT = 1; CALL; } break; \
-      case 2: { constexpr int WT = 2; CALL; } break; \
-      case 3: { constexpr int WT = 3; CALL; } break; \
-      case 4: { constexpr int WT = 4; CALL; } break; \
-      case 5:                                        \
-      case 6: { constexpr int WT = 6; CALL; } break; \
-      default: { constexpr int WT = 8; CALL; } break; \
-    }                                                \
+// Kernel variants: NW = u32 register words per plane; CN / CK = compile-time board width and
+// run length (0 = run time).  The boards people actually train on get fully specialised code
+// (immediate shift amounts, unrolled run doubling); everything else takes the generic form.
+#define MNK_CASE(NWv, CNv, CKv, ...)                      \
+  {                                                       \
+    constexpr int NW = NWv, CN = CNv, CK = CKv;           \
+    __VA_ARGS__;                                          \
+  }
+#define MNK_DISPATCH(g, ...)                                                          \
+  do {                                                                                \
+    if ((g).n == 9 && (g).k == 5 && (g).NW == 3) MNK_CASE(3, 9, 5, __VA_ARGS__)       \
+    else if ((g).n == 3 && (g).k == 3 && (g).NW == 1) MNK_CASE(1, 3, 3, __VA_ARGS__)  \
+    else if ((g).n == 13 && (g).k == 5 && (g).NW == 6) MNK_CASE(6, 13, 5, __VA_ARGS__) \
+    else if ((g).n == 15 && (g).k == 5 && (g).NW == 8) MNK_CASE(8, 15, 5, __VA_ARGS__) \
+    else if ((g).n == 19 && (g).k == 5 && (g).NW == 12) MNK_CASE(12, 19, 5, __VA_ARGS__) \
+    else if ((g).NW <= 2) MNK_CASE(2, 0, 0, __VA_ARGS__)                              \
+    else if ((g).NW <= 4) MNK_CASE(4, 0, 0, __VA_ARGS__)                              \
+    else if ((g).NW <= 8) MNK_CASE(8, 0, 0, __VA_ARGS__)                              \
+    else MNK_CASE(16, 0, 0, __VA_ARGS__)                                              \
   } while (0)
+#define MNK_K(name) HIP_KERNEL_NAME(name<NW, CN, CK>)
 
 // ------------------------------------------------------------------ reset
 __global__ void k_reset_idx(uint64_t* planes, uint32_t* meta, int64_t N, int W, const int64_t* idx, int64_t R,
@@ -97,7 +106,7 @@ __global__ void k_reset_mask(uint64_t* planes, uint32_t* meta, int64_t N, int W,
 }
 
 // ------------------------------------------------------------------ step (full batch, fused write-out)
-template <int WT>
+template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
 k_step_full(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions, float* rewards,
             uint8_t* dones, uint8_t* legal_mask, float* obs, int32_t* err, uint32_t flags, int vec_ok) {
@@ -109,14 +118,14 @@ k_step_full(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_
   MnkStage st = mnk_stage_carve(lds_raw, g, B);
   if (emit) mnk_stage_tables(st, g, B, tid, B);
   if (i < N) {
-    MnkEnv<WT> e;
-    env_load<WT>(e, planes, meta, N, g.W, i);
-    MnkPly ply = env_play<WT>(g, e, actions[i], (flags & MNK_STEP_STRICT) != 0);
+    MnkEnv<NW> e;
+    env_load<NW>(e, planes, meta, N, g.W, i);
+    MnkPly ply = env_play<NW, CN, CK>(g, e, actions[i], (flags & MNK_STEP_STRICT) != 0);
     if (ply.err) mnk_report(err, ply.err, i);
-    else env_store<WT>(e, planes, meta, N, g.W, i);
+    else env_store<NW>(e, planes, meta, N, g.W, i);
     rewards[i] = ply.win ? 1.0f : 0.0f;   // :75-77
     dones[i] = ply.done ? 1 : 0;          // :79-80
-    if (emit) mnk_stage_put<WT>(st, g, B, tid, e.p[0], e.p[1], false);
+    if (emit) mnk_stage_put<NW>(st, g, B, tid, e.p[0], e.p[1], false);
   }
   if (emit) {
     __syncthreads();
@@ -128,7 +137,7 @@ k_step_full(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_
 }
 
 // step_subset: lane j plays env active_idx[j]; rewards / dones were zero-filled by the launcher
-template <int WT>
+template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
 k_step_subset(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions,
               const int64_t* active_idx, int64_t A, float* rewards, uint8_t* dones, int32_t* err,
@@ -138,17 +147,17 @@ k_step_subset(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int6
   int64_t i = active_idx[j];
   if (i < 0) i += N;
   if (i < 0 || i >= N) { mnk_report(err, MNK_ERR_ACTION_RANGE, active_idx[j]); return; }
-  MnkEnv<WT> e;
-  env_load<WT>(e, planes, meta, N, g.W, i);
-  MnkPly ply = env_play<WT>(g, e, actions[j], (flags & MNK_STEP_STRICT) != 0);
+  MnkEnv<NW> e;
+  env_load<NW>(e, planes, meta, N, g.W, i);
+  MnkPly ply = env_play<NW, CN, CK>(g, e, actions[j], (flags & MNK_STEP_STRICT) != 0);
   if (ply.err) { mnk_report(err, ply.err, i); return; }
-  env_store<WT>(e, planes, meta, N, g.W, i);
+  env_store<NW>(e, planes, meta, N, g.W, i);
   rewards[i] = ply.win ? 1.0f : 0.0f;
   dones[i] = ply.done ? 1 : 0;
 }
 
 // ------------------------------------------------------------------ observe / unpack
-template <int WT>
+template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
 k_observe(MnkGeom g, const uint64_t* planes, int64_t N, const int64_t* flip_side, float* obs,
           uint8_t* legal_mask, int fix_empty, int vec_ok) {
@@ -159,16 +168,12 @@ k_observe(MnkGeom g, const uint64_t* planes, int64_t N, const int64_t* flip_side
   MnkStage st = mnk_stage_carve(lds_raw, g, B);
   mnk_stage_tables(st, g, B, tid, B);
   if (i < N) {
-    uint64_t a[WT], b[WT];
+    uint32_t p0[NW], p1[NW];
+    plane_load<NW>(p0, planes, N, g.W, i);
+    plane_load<NW>(p1, planes + (int64_t)g.W * N, N, g.W, i);
     const bool flip = flip_side && flip_side[i] == 1;  // wrapper:104-106
-#pragma unroll
-    for (int w = 0; w < WT; ++w) {
-      const uint64_t p0 = w < g.W ? planes[(int64_t)(0 * g.W + w) * N + i] : 0ull;
-      const uint64_t p1 = w < g.W ? planes[(int64_t)(1 * g.W + w) * N + i] : 0ull;
-      a[w] = flip ? p1 : p0;
-      b[w] = flip ? p0 : p1;
-    }
-    mnk_stage_put<WT>(st, g, B, tid, a, b, fix_empty != 0);
+    if (flip) mnk_stage_put<NW>(st, g, B, tid, p1, p0, fix_empty != 0);
+    else mnk_stage_put<NW>(st, g, B, tid, p0, p1, fix_empty != 0);
   }
   __syncthreads();
   const int64_t left = N - env0;
@@ -201,19 +206,18 @@ __global__ void k_pack_boards(MnkGeom g, const float* boards, uint64_t* planes, 
 }
 
 // ------------------------------------------------------------------ RandomPolicy
-template <int WT>
+template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
 k_sample_legal(MnkGeom g, const uint64_t* planes, int64_t N, uint64_t seed, uint64_t step, int64_t env_id0,
                uint32_t stream_id, int64_t* actions) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  MnkEnv<WT> e;
-#pragma unroll
-  for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-    for (int w = 0; w < WT; ++w) e.p[pl][w] = (w < g.W) ? planes[(int64_t)(pl * g.W + w) * N + i] : 0ull;
+  MnkEnv<NW> e;
+  plane_load<NW>(e.p[0], planes, N, g.W, i);
+  plane_load<NW>(e.p[1], planes + (int64_t)g.W * N, N, g.W, i);
+  e.meta = 0u;
   const uint32_t x = mnk_rand_u32(seed, (uint64_t)(env_id0 + i), step, stream_id);
-  actions[i] = env_pick_legal<WT>(g, e, x);
+  actions[i] = env_pick_legal<NW, CN>(g, e, x);
 }
 
 // ------------------------------------------------------------------ fused random rollout
@@ -221,15 +225,15 @@ k_sample_legal(MnkGeom g, const uint64_t* planes, int64_t N, uint64_t seed, uint
 // store of the state per launch plus the 36-byte (9x9) record of every ply.
 // Wave-level bookkeeping: finished games are counted with ballot + popcount (one scalar
 // add per wave and ply) and folded into the global counters by one lane at the end.
-template <int WT>
+template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(64)
 k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed, uint64_t step0,
                  int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, unsigned long long* stats) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < N;
   const int64_t ii = live ? i : N - 1;  // idle lanes shadow the last env, never store
-  MnkEnv<WT> e;
-  env_load<WT>(e, planes, meta, N, g.W, ii);
+  MnkEnv<NW> e;
+  env_load<NW>(e, planes, meta, N, g.W, ii);
   const uint64_t env = (uint64_t)(env_id0 + ii);
   unsigned long long n_done = 0, n_black = 0, n_white = 0, n_draw = 0;
   uint32_t len_sum = 0;
@@ -239,15 +243,13 @@ k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, 
     if (t > 0 && (step & 3) == 0) blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
     const uint32_t x = philox_word(blk, (uint32_t)(step & 3));
     if (rec_planes && live) {
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-        for (int w = 0; w < WT; ++w)
-          if (w < g.W) rec_planes[(((int64_t)t * 2 + pl) * g.W + w) * N + i] = e.p[pl][w];
+      uint64_t* rp = rec_planes + (int64_t)t * 2 * g.W * N;
+      plane_store<NW>(e.p[0], rp, N, g.W, i);
+      plane_store<NW>(e.p[1], rp + (int64_t)g.W * N, N, g.W, i);
     }
     const uint32_t side = e.meta & 1u;
-    const int a = env_pick_legal<WT>(g, e, x);
-    const MnkPly ply = env_play<WT>(g, e, a, false);
+    const int a = env_pick_legal<NW, CN>(g, e, x);
+    const MnkPly ply = env_play<NW, CN, CK>(g, e, a, false);
     if (rec_meta && live)
       rec_meta[(int64_t)t * N + i] = (uint32_t)a | ((ply.win ? 1u : 0u) << MNK_REC_REWARD_SHIFT) |
                                      ((ply.done ? 1u : 0u) << MNK_REC_DONE_BIT) | (side << MNK_REC_SIDE_BIT);
@@ -257,9 +259,9 @@ k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, 
     n_white += __popcll(__ballot(fin && ply.win && side == 1));
     n_draw += __popcll(__ballot(fin && !ply.win));
     if (fin) len_sum += e.meta >> 1;
-    if (ply.done) env_clear<WT>(e);  // env.reset(nonzero(done)) :34-44
+    if (ply.done) env_clear<NW>(e);  // env.reset(nonzero(done)) :34-44
   }
-  if (live) env_store<WT>(e, planes, meta, N, g.W, i);
+  if (live) env_store<NW>(e, planes, meta, N, g.W, i);
   if (stats) {
     unsigned long long ls = len_sum;
 #pragma unroll
@@ -284,17 +286,17 @@ struct SpAgent {
 };
 
 // wrapper:39-63 up to (not including) the opponent's reply, for one env
-template <int WT>
-__device__ __forceinline__ SpAgent sp_agent_half(const MnkGeom& g, MnkEnv<WT>& e, int64_t action, bool pending,
+template <int NW, int CN, int CK>
+__device__ __forceinline__ SpAgent sp_agent_half(const MnkGeom& g, MnkEnv<NW>& e, int64_t action, bool pending,
                                                  int64_t& side, const int64_t* forced_side, uint64_t seed,
                                                  uint64_t step, uint64_t env, int64_t i, int32_t* err) {
   SpAgent a;
   a.reward = 0.0f; a.term = false; a.was_reset = pending;
   if (pending) {
-    env_clear<WT>(e);  // wrapper:41 env.reset(reset_idxs)
+    env_clear<NW>(e);  // wrapper:41 env.reset(reset_idxs)
     side = forced_side ? (forced_side[i] & 1) : (int64_t)(mnk_rand_u32(seed, env, step, MNK_STREAM_SIDE) >> 31);  // :43-45
   } else {
-    const MnkPly ply = env_play<WT>(g, e, action, false);  // :51
+    const MnkPly ply = env_play<NW, CN, CK>(g, e, action, false);  // :51
     if (ply.err) mnk_report(err, ply.err, i);
     a.reward = ply.win ? 1.0f : 0.0f;  // :53
     a.term = ply.done;                 // :54
@@ -304,7 +306,7 @@ __device__ __forceinline__ SpAgent sp_agent_half(const MnkGeom& g, MnkEnv<WT>& e
   return a;
 }
 
-template <int WT>
+template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
 k_selfplay_pre(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions,
                const uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
@@ -318,13 +320,13 @@ k_selfplay_pre(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int
   MnkStage st = mnk_stage_carve(lds_raw, g, B);
   if (emit) mnk_stage_tables(st, g, B, tid, B);
   if (i < N) {
-    MnkEnv<WT> e;
-    env_load<WT>(e, planes, meta, N, g.W, i);
+    MnkEnv<NW> e;
+    env_load<NW>(e, planes, meta, N, g.W, i);
     int64_t side = agent_side[i];
     const bool pend = pending[i] != 0;
-    const SpAgent a = sp_agent_half<WT>(g, e, actions[i], pend, side, forced_side, seed, step,
+    const SpAgent a = sp_agent_half<NW, CN, CK>(g, e, actions[i], pend, side, forced_side, seed, step,
                                         (uint64_t)(env_id0 + i), i, err);
-    env_store<WT>(e, planes, meta, N, g.W, i);
+    env_store<NW>(e, planes, meta, N, g.W, i);
     if (pend) agent_side[i] = side;
     rewards[i] = a.reward;
     terminated[i] = a.term ? 1 : 0;
@@ -332,8 +334,8 @@ k_selfplay_pre(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int
     if (emit) {
       // wrapper:83-89: the mover sees itself in channel 0
       const bool white_to_move = (e.meta & 1u) != 0;
-      if (white_to_move) mnk_stage_put<WT>(st, g, B, tid, e.p[1], e.p[0], !a.need_opp);
-      else mnk_stage_put<WT>(st, g, B, tid, e.p[0], e.p[1], !a.need_opp);
+      if (white_to_move) mnk_stage_put<NW>(st, g, B, tid, e.p[1], e.p[0], !a.need_opp);
+      else mnk_stage_put<NW>(st, g, B, tid, e.p[0], e.p[1], !a.need_opp);
     }
   }
   if (emit) {
@@ -345,7 +347,7 @@ k_selfplay_pre(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int
   }
 }
 
-template <int WT>
+template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
 k_selfplay_post(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* opp_actions,
                 const uint8_t* sp_flags, const int64_t* agent_side, float* rewards, uint8_t* terminated,
@@ -358,15 +360,15 @@ k_selfplay_post(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const in
   MnkStage st = mnk_stage_carve(lds_raw, g, B);
   if (emit) mnk_stage_tables(st, g, B, tid, B);
   if (i < N) {
-    MnkEnv<WT> e;
-    env_load<WT>(e, planes, meta, N, g.W, i);
+    MnkEnv<NW> e;
+    env_load<NW>(e, planes, meta, N, g.W, i);
     const uint32_t f = sp_flags[i];
     float rew = rewards[i];
     bool term = terminated[i] != 0;
     if (f & MNK_SP_NEED_OPP) {
-      const MnkPly ply = env_play<WT>(g, e, opp_actions[i], false);  // wrapper:96
+      const MnkPly ply = env_play<NW, CN, CK>(g, e, opp_actions[i], false);  // wrapper:96
       if (ply.err) mnk_report(err, ply.err, i);
-      else env_store<WT>(e, planes, meta, N, g.W, i);
+      else env_store<NW>(e, planes, meta, N, g.W, i);
       if (!(f & MNK_SP_WAS_RESET)) {  // :46 ignores the reply's outcome after a reset
         rew -= ply.win ? 1.0f : 0.0f;  // :62
         term = ply.done;               // :63
@@ -376,8 +378,8 @@ k_selfplay_post(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const in
     }
     pending[i] = term ? 1 : 0;  // :65
     if (emit) {
-      if (agent_side[i] == 1) mnk_stage_put<WT>(st, g, B, tid, e.p[1], e.p[0], true);  // :104-106
-      else mnk_stage_put<WT>(st, g, B, tid, e.p[0], e.p[1], true);
+      if (agent_side[i] == 1) mnk_stage_put<NW>(st, g, B, tid, e.p[1], e.p[0], true);  // :104-106
+      else mnk_stage_put<NW>(st, g, B, tid, e.p[0], e.p[1], true);
     }
   }
   if (emit) {
@@ -390,7 +392,7 @@ k_selfplay_post(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const in
 }
 
 // the whole wrapper.step in one launch when the opponent is RandomPolicy (policy.py:13-29)
-template <int WT>
+template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
 k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions,
                        uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
@@ -404,28 +406,28 @@ k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, c
   MnkStage st = mnk_stage_carve(lds_raw, g, B);
   if (emit) mnk_stage_tables(st, g, B, tid, B);
   if (i < N) {
-    MnkEnv<WT> e;
-    env_load<WT>(e, planes, meta, N, g.W, i);
+    MnkEnv<NW> e;
+    env_load<NW>(e, planes, meta, N, g.W, i);
     int64_t side = agent_side[i];
     const bool pend = pending[i] != 0;
     const uint64_t env = (uint64_t)(env_id0 + i);
-    SpAgent a = sp_agent_half<WT>(g, e, actions[i], pend, side, forced_side, seed, step, env, i, err);
+    SpAgent a = sp_agent_half<NW, CN, CK>(g, e, actions[i], pend, side, forced_side, seed, step, env, i, err);
     if (a.need_opp) {
-      const int oa = env_pick_legal<WT>(g, e, mnk_rand_u32(seed, env, step, MNK_STREAM_OPP));
-      const MnkPly ply = env_play<WT>(g, e, oa, false);
+      const int oa = env_pick_legal<NW, CN>(g, e, mnk_rand_u32(seed, env, step, MNK_STREAM_OPP));
+      const MnkPly ply = env_play<NW, CN, CK>(g, e, oa, false);
       if (!a.was_reset) {
         a.reward -= ply.win ? 1.0f : 0.0f;
         a.term = ply.done;
       }
     }
-    env_store<WT>(e, planes, meta, N, g.W, i);
+    env_store<NW>(e, planes, meta, N, g.W, i);
     if (pend) agent_side[i] = side;
     rewards[i] = a.reward;
     terminated[i] = a.term ? 1 : 0;
     pending[i] = a.term ? 1 : 0;
     if (emit) {
-      if (side == 1) mnk_stage_put<WT>(st, g, B, tid, e.p[1], e.p[0], true);
-      else mnk_stage_put<WT>(st, g, B, tid, e.p[0], e.p[1], true);
+      if (side == 1) mnk_stage_put<NW>(st, g, B, tid, e.p[1], e.p[0], true);
+      else mnk_stage_put<NW>(st, g, B, tid, e.p[0], e.p[1], true);
     }
   }
   if (emit) {
@@ -516,7 +518,7 @@ k_sample_logits(const float* logits, const uint8_t* mask, int64_t N, int C, uint
 }
 
 // ------------------------------------------------------------------ records -> RolloutBuffer layout
-template <int WT>
+template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
 k_unpack_records(MnkGeom g, const uint64_t* rec_planes, const uint32_t* rec_meta, int64_t N, float* obs,
                  uint8_t* masks, int64_t* actions, float* rewards, uint8_t* dones, int vec_ok) {
@@ -534,16 +536,13 @@ k_unpack_records(MnkGeom g, const uint64_t* rec_planes, const uint32_t* rec_meta
     if (rewards) rewards[t * N + i] = (float)(int8_t)((mw >> MNK_REC_REWARD_SHIFT) & 0xFFu);
     if (dones) dones[t * N + i] = (uint8_t)((mw >> MNK_REC_DONE_BIT) & 1u);
     if (emit) {
-      uint64_t a[WT], b[WT];
+      uint32_t p0[NW], p1[NW];
+      const uint64_t* rp = rec_planes + t * 2 * g.W * N;
+      plane_load<NW>(p0, rp, N, g.W, i);
+      plane_load<NW>(p1, rp + (int64_t)g.W * N, N, g.W, i);
       const bool flip = ((mw >> MNK_REC_SIDE_BIT) & 1u) != 0;  // the mover sees itself in channel 0
-#pragma unroll
-      for (int w = 0; w < WT; ++w) {
-        const uint64_t p0 = w < g.W ? rec_planes[((t * 2 + 0) * g.W + w) * N + i] : 0ull;
-        const uint64_t p1 = w < g.W ? rec_planes[((t * 2 + 1) * g.W + w) * N + i] : 0ull;
-        a[w] = flip ? p1 : p0;
-        b[w] = flip ? p0 : p1;
-      }
-      mnk_stage_put<WT>(st, g, B, tid, a, b, false);
+      if (flip) mnk_stage_put<NW>(st, g, B, tid, p1, p0, false);
+      else mnk_stage_put<NW>(st, g, B, tid, p0, p1, false);
     }
   }
   if (emit) {
@@ -634,9 +633,9 @@ int mnk_observe(const uint64_t* planes, const uint32_t* meta, int64_t N, int m, 
   if (N == 0 || (!obs && !legal_mask)) return MNK_OK;
   const int B = mnk_block_envs(N);
   const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
-  const size_t lds = mnk_stage_bytes(g.W, g.C, B);
+  const size_t lds = mnk_stage_bytes(g.NW, g.C, B);
   const dim3 grid((unsigned)((N + B - 1) / B));
-  MNK_DISPATCH_W(g.W, hipLaunchKernelGGL(k_observe<WT>, grid, dim3(B), lds, (hipStream_t)stream, g, planes, N,
+  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_observe), grid, dim3(B), lds, (hipStream_t)stream, g, planes, N,
                                          flip_side, obs, legal_mask, fix_empty_mask, vec_ok));
   return mnk_launch_status("observe");
 }
@@ -672,9 +671,9 @@ int mnk_step(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, c
     const int B = mnk_block_envs(N);
     const bool emit = legal_mask || obs;
     const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
-    const size_t lds = emit ? mnk_stage_bytes(g.W, g.C, B) : 0;
+    const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B) : 0;
     const dim3 grid((unsigned)((N + B - 1) / B));
-    MNK_DISPATCH_W(g.W, hipLaunchKernelGGL(k_step_full<WT>, grid, dim3(B), lds, s, g, planes, meta, N, actions,
+    MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_step_full), grid, dim3(B), lds, s, g, planes, meta, N, actions,
                                            rewards, dones, legal_mask, obs, err, flags, vec_ok));
     return mnk_launch_status("step");
   }
@@ -684,7 +683,7 @@ int mnk_step(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, c
   if (A > 0) {
     const int B = 64;
     const dim3 grid((unsigned)((A + B - 1) / B));
-    MNK_DISPATCH_W(g.W, hipLaunchKernelGGL(k_step_subset<WT>, grid, dim3(B), 0, s, g, planes, meta, N, actions,
+    MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_step_subset), grid, dim3(B), 0, s, g, planes, meta, N, actions,
                                            active_idx, A, rewards, dones, err, flags));
     rc = mnk_launch_status("step_subset");
     if (rc != MNK_OK) return rc;
@@ -702,7 +701,7 @@ int mnk_sample_legal(const uint64_t* planes, int64_t N, int m, int n, uint64_t s
   if (N == 0) return MNK_OK;
   const int B = 64;
   const dim3 grid((unsigned)((N + B - 1) / B));
-  MNK_DISPATCH_W(g.W, hipLaunchKernelGGL(k_sample_legal<WT>, grid, dim3(B), 0, (hipStream_t)stream, g, planes, N, seed,
+  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_sample_legal), grid, dim3(B), 0, (hipStream_t)stream, g, planes, N, seed,
                                          step, env_id0, (uint32_t)stream_id, actions));
   return mnk_launch_status("sample_legal");
 }
@@ -717,7 +716,7 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   if (N == 0 || T == 0) return MNK_OK;
   const int B = 64;
   const dim3 grid((unsigned)((N + B - 1) / B));
-  MNK_DISPATCH_W(g.W, hipLaunchKernelGGL(k_rollout_random<WT>, grid, dim3(B), 0, (hipStream_t)stream, g, planes, meta,
+  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_rollout_random), grid, dim3(B), 0, (hipStream_t)stream, g, planes, meta,
                                          N, T, seed, step0, env_id0, rec_planes, rec_meta,
                                          (unsigned long long*)stats));
   return mnk_launch_status("rollout_random");
@@ -736,9 +735,9 @@ int mnk_selfplay_pre(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, 
   const int B = mnk_block_envs(N);
   const bool emit = opp_obs || opp_mask;
   const int vec_ok = (aligned16(opp_obs) ? 1 : 0) | (aligned16(opp_mask) ? 2 : 0);
-  const size_t lds = emit ? mnk_stage_bytes(g.W, g.C, B) : 0;
+  const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B) : 0;
   const dim3 grid((unsigned)((N + B - 1) / B));
-  MNK_DISPATCH_W(g.W, hipLaunchKernelGGL(k_selfplay_pre<WT>, grid, dim3(B), lds, (hipStream_t)stream, g, planes, meta,
+  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_pre), grid, dim3(B), lds, (hipStream_t)stream, g, planes, meta,
                                          N, actions, pending, agent_side, forced_side, seed, step, env_id0, rewards,
                                          terminated, sp_flags, opp_obs, opp_mask, err, vec_ok));
   return mnk_launch_status("selfplay_pre");
@@ -756,9 +755,9 @@ int mnk_selfplay_post(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n,
   const int B = mnk_block_envs(N);
   const bool emit = obs || legal_mask;
   const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
-  const size_t lds = emit ? mnk_stage_bytes(g.W, g.C, B) : 0;
+  const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B) : 0;
   const dim3 grid((unsigned)((N + B - 1) / B));
-  MNK_DISPATCH_W(g.W, hipLaunchKernelGGL(k_selfplay_post<WT>, grid, dim3(B), lds, (hipStream_t)stream, g, planes,
+  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_post), grid, dim3(B), lds, (hipStream_t)stream, g, planes,
                                          meta, N, opp_actions, sp_flags, agent_side, rewards, terminated, pending, obs,
                                          legal_mask, err, vec_ok));
   return mnk_launch_status("selfplay_post");
@@ -776,9 +775,9 @@ int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m,
   const int B = mnk_block_envs(N);
   const bool emit = obs || legal_mask;
   const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
-  const size_t lds = emit ? mnk_stage_bytes(g.W, g.C, B) : 0;
+  const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B) : 0;
   const dim3 grid((unsigned)((N + B - 1) / B));
-  MNK_DISPATCH_W(g.W, hipLaunchKernelGGL(k_selfplay_step_random<WT>, grid, dim3(B), lds, (hipStream_t)stream, g,
+  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_step_random), grid, dim3(B), lds, (hipStream_t)stream, g,
                                          planes, meta, N, actions, pending, agent_side, forced_side, seed, step,
                                          env_id0, rewards, terminated, obs, legal_mask, err, vec_ok));
   return mnk_launch_status("selfplay_step_random");
@@ -807,9 +806,9 @@ int mnk_unpack_records(const uint64_t* rec_planes, const uint32_t* rec_meta, int
   const bool obs_vec = aligned16(obs) && ((N * 2 * g.C * 4) % 16 == 0);
   const bool mask_vec = aligned16(masks) && ((N * g.C) % 16 == 0);
   const int vec_ok = (obs_vec ? 1 : 0) | (mask_vec ? 2 : 0);
-  const size_t lds = emit ? mnk_stage_bytes(g.W, g.C, B) : 0;
+  const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B) : 0;
   const dim3 grid((unsigned)((N + B - 1) / B), (unsigned)T);
-  MNK_DISPATCH_W(g.W, hipLaunchKernelGGL(k_unpack_records<WT>, grid, dim3(B), lds, (hipStream_t)stream, g, rec_planes,
+  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_unpack_records), grid, dim3(B), lds, (hipStream_t)stream, g, rec_planes,
                                          rec_meta, N, obs, masks, actions, rewards, dones, vec_ok));
   return mnk_launch_status("unpack_records");
 }
