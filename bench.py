@@ -38,10 +38,12 @@ def parse():
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--board", type=str, default="9x9x5")
-    ap.add_argument("--chunk", type=int, default=64, help="plies per launch of the fused rollout kernel")
+    ap.add_argument("--chunk", type=int, default=256,
+                    help="plies per launch of the fused rollout kernel (256 = the reference's n_steps, train.py:246)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, host cores): the CPU share of one GPU")
     ap.add_argument("--no-api-path", action="store_true", help="skip the extra per-step-launch measurement")
     return ap.parse_args()
 
@@ -57,7 +59,7 @@ def state_bytes(words):
     return 16 * words + 4
 
 
-def cpu_baseline(env, seconds):
+def cpu_baseline(env, seconds, threads=0):
     """The oracle's torch-eager restatement of the reference env (conv2d win scan) and of
     RandomPolicy (multinomial), timed on the host cores from the GPU env's current (stationary)
     position.  Test infrastructure used as the reported CPU baseline -- never the product path."""
@@ -65,6 +67,8 @@ def cpu_baseline(env, seconds):
     from oracle.policies import OracleRandomPolicy
 
     n = env.num_envs
+    threads = threads or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     ora = OracleVectorEnv(env.m, env.n, env.k, n)
     ora.boards.copy_(env.boards.cpu())
     ora.current_player.copy_(env.current_player.cpu())
@@ -263,7 +267,7 @@ def main():
         if world == 1 and not args.no_api_path:
             out["api_path_env_steps_per_s"] = api_path_rate(env, args.seed)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(env, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(env, args.cpu_seconds, args.cpu_threads)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -65,6 +65,13 @@ extern "C" {
 #define MNK_REC_DONE_BIT 24
 #define MNK_REC_SIDE_BIT 25
 
+/* rollout statistics: int64[MNK_STATS_REPLICAS][MNK_STATS_STRIDE]; a counter's value is the sum of
+ * its replicas (column j of every row).  Replication keeps thousands of waves from serialising
+ * their atomic adds on one address. */
+#define MNK_STATS_REPLICAS 64
+#define MNK_STATS_STRIDE 8
+#define MNK_STATS_COUNTERS 5 /* episodes finished, black wins, white wins, draws, sum of episode lengths */
+
 /* Philox streams (oracle/philox.py restates the generator) */
 #define MNK_STREAM_MOVE 0
 #define MNK_STREAM_OPP 1
@@ -155,7 +162,8 @@ int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m,
 /* ---- the random-policy rollout of BASELINE.json (RandomPolicy.act -> env.step -> env.reset(done)),
  * T plies per env in one launch with the state held in registers.
  * rec_planes u64[T][2][W][N]: absolute planes BEFORE each ply; rec_meta u32[T][N]: MNK_REC_* word;
- * stats (optional) int64[5] += {episodes finished, black wins, white wins, draws, sum of episode lengths}.
+ * stats (optional) int64[MNK_STATS_REPLICAS][MNK_STATS_STRIDE] += {episodes finished, black wins,
+ * white wins, draws, sum of episode lengths} spread over the replicas (sum the rows to read a counter).
  * rec_planes / rec_meta may be NULL (state-only rollout). */
 int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, int T,
                        uint64_t seed, uint64_t step0, int64_t env_id0,

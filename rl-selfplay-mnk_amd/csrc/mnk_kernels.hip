@@ -229,6 +229,8 @@ template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(64)
 k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed, uint64_t step0,
                  int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, unsigned long long* stats) {
+  // one full wave of 64 envs per workgroup: half-filled waves were measured and are slower
+  // (gfx950 does not skip the idle half of a wave64), see DESIGN.md section 5
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < N;
   const int64_t ii = live ? i : N - 1;  // idle lanes shadow the last env, never store
@@ -263,15 +265,22 @@ k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, 
   }
   if (live) env_store<NW>(e, planes, meta, N, g.W, i);
   if (stats) {
-    unsigned long long ls = len_sum;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ls += __shfl_down(ls, off, 64);
+    // sum of the lanes' episode lengths through one LDS word (only the lanes still running take part)
+    __shared__ unsigned int lds_len;
+    if (threadIdx.x == 0) lds_len = 0u;
+    __syncthreads();
+    if (len_sum) atomicAdd(&lds_len, len_sum);
+    __syncthreads();
+    const unsigned long long ls = lds_len;
     if ((threadIdx.x & 63) == 0) {
-      if (n_done) atomicAdd(&stats[0], n_done);
-      if (n_black) atomicAdd(&stats[1], n_black);
-      if (n_white) atomicAdd(&stats[2], n_white);
-      if (n_draw) atomicAdd(&stats[3], n_draw);
-      if (ls) atomicAdd(&stats[4], ls);
+      // one atomic per counter per wave would serialise thousands of adds on five addresses
+      // (~11 ns each); the counters are replicated over MNK_STATS_REPLICAS cache lines instead
+      unsigned long long* slot = stats + (size_t)(blockIdx.x % MNK_STATS_REPLICAS) * MNK_STATS_STRIDE;
+      if (n_done) atomicAdd(&slot[0], n_done);
+      if (n_black) atomicAdd(&slot[1], n_black);
+      if (n_white) atomicAdd(&slot[2], n_white);
+      if (n_draw) atomicAdd(&slot[3], n_draw);
+      if (ls) atomicAdd(&slot[4], ls);
     }
   }
 }

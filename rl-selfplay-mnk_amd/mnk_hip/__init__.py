@@ -18,6 +18,7 @@ ERR_NONE, ERR_ACTION_RANGE, ERR_ILLEGAL_MOVE = 0, 1, 2
 STEP_STRICT = 1
 SP_NEED_OPP, SP_WAS_RESET = 1, 2
 STREAM_MOVE, STREAM_OPP, STREAM_SIDE, STREAM_GUMBEL = 0, 1, 2, 3
+STATS_REPLICAS, STATS_STRIDE, STATS_COUNTERS = 64, 8, 5
 REC_ACTION_MASK, REC_REWARD_SHIFT, REC_DONE_BIT, REC_SIDE_BIT = 0xFFFF, 16, 24, 25
 
 _vp, _i, _i64, _u64, _u32, _f = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint32,

@@ -57,8 +57,13 @@ class RandomRollout:
         self.seed = int(seed)
         self.env_id0 = int(env_id0)
         self.step = 0  # plies played per env so far = Philox step counter
-        # [episodes finished, black wins, white wins, draws, sum of finished-episode lengths]
-        self.stats = torch.zeros(5, dtype=torch.int64, device=env._dev)
+        # replicated device counters (see MNK_STATS_REPLICAS in include/mnk_hip.h)
+        self._stats = torch.zeros((mnk_hip.STATS_REPLICAS, mnk_hip.STATS_STRIDE), dtype=torch.int64, device=env._dev)
+
+    @property
+    def stats(self) -> torch.Tensor:
+        """int64[5]: episodes finished, black wins, white wins, draws, sum of finished-episode lengths"""
+        return self._stats.sum(dim=0)[:mnk_hip.STATS_COUNTERS]
 
     def alloc(self, steps: int) -> RolloutRecords:
         env = self.env
@@ -79,7 +84,7 @@ class RandomRollout:
             mnk_hip.call("mnk_rollout_random", mnk_hip.ptr(env._planes), mnk_hip.ptr(env._meta), env.num_envs,
                          env.m, env.n, env.k, steps, self.seed, self.step, self.env_id0,
                          mnk_hip.ptr(out.planes) if record else None, mnk_hip.ptr(out.meta) if record else None,
-                         mnk_hip.ptr(self.stats), env._stream())
+                         mnk_hip.ptr(self._stats), env._stream())
         self.step += steps
         return out if record else None
 
