@@ -179,38 +179,40 @@ struct MnkEnv {
 };
 
 // planes u64[2][W][N] in memory <-> NW u32 words per plane in registers
-template <int NW>
+// EXACT: the plane has exactly (NW+1)/2 memory words (true for the specialised boards), so the
+// wave-uniform "does this word exist" tests fold away
+template <int NW, bool EXACT = false>
 __device__ __forceinline__ void plane_load(uint32_t (&x)[NW], const uint64_t* plane, int64_t N, int W, int64_t i) {
 #pragma unroll
   for (int q = 0; q < (NW + 1) / 2; ++q) {
-    const uint64_t v = (q < W) ? plane[(int64_t)q * N + i] : 0ull;
+    const uint64_t v = (EXACT || q < W) ? plane[(int64_t)q * N + i] : 0ull;
     x[2 * q] = (uint32_t)v;
     if (2 * q + 1 < NW) x[2 * q + 1] = (uint32_t)(v >> 32);
   }
 }
 
-template <int NW>
+template <int NW, bool EXACT = false>
 __device__ __forceinline__ void plane_store(const uint32_t (&x)[NW], uint64_t* plane, int64_t N, int W, int64_t i) {
 #pragma unroll
   for (int q = 0; q < (NW + 1) / 2; ++q) {
     const uint64_t hi = (2 * q + 1 < NW) ? (uint64_t)x[2 * q + 1] : 0ull;
-    if (q < W) plane[(int64_t)q * N + i] = (uint64_t)x[2 * q] | (hi << 32);
+    if (EXACT || q < W) plane[(int64_t)q * N + i] = (uint64_t)x[2 * q] | (hi << 32);
   }
 }
 
-template <int NW>
+template <int NW, bool EXACT = false>
 __device__ __forceinline__ void env_load(MnkEnv<NW>& e, const uint64_t* planes, const uint32_t* meta, int64_t N,
                                          int W, int64_t i) {
-  plane_load<NW>(e.p[0], planes, N, W, i);
-  plane_load<NW>(e.p[1], planes + (int64_t)W * N, N, W, i);
+  plane_load<NW, EXACT>(e.p[0], planes, N, W, i);
+  plane_load<NW, EXACT>(e.p[1], planes + (int64_t)W * N, N, W, i);
   e.meta = meta[i];
 }
 
-template <int NW>
+template <int NW, bool EXACT = false>
 __device__ __forceinline__ void env_store(const MnkEnv<NW>& e, uint64_t* planes, uint32_t* meta, int64_t N, int W,
                                           int64_t i) {
-  plane_store<NW>(e.p[0], planes, N, W, i);
-  plane_store<NW>(e.p[1], planes + (int64_t)W * N, N, W, i);
+  plane_store<NW, EXACT>(e.p[0], planes, N, W, i);
+  plane_store<NW, EXACT>(e.p[1], planes + (int64_t)W * N, N, W, i);
   meta[i] = e.meta;
 }
 
@@ -235,10 +237,12 @@ __device__ __forceinline__ int env_pick_legal(const MnkGeom& g, const MnkEnv<NW>
   uint32_t legal[NW];
   env_legal<NW>(g, e, legal);
   const int nl = bs_popcount<NW>(legal);
-  if (nl == 0) return (int)__umulhi(x, (uint32_t)g.C);
-  const int r = (int)__umulhi(x, (uint32_t)nl);
+  // branch-free: a full board (nl == 0) draws over all C cells; the select below then runs on
+  // an empty string and its result is discarded
+  const int r = (int)__umulhi(x, (uint32_t)(nl ? nl : g.C));
   const uint32_t bit = (uint32_t)bs_select<NW>(legal, r);
-  return (int)(bit - (CN ? bit / (uint32_t)(CN + 1) : mnk_div(bit, g.magic_stride)));
+  const int cell = (int)(bit - (CN ? bit / (uint32_t)(CN + 1) : mnk_div(bit, g.magic_stride)));
+  return nl ? cell : r;
 }
 
 struct MnkPly {
@@ -247,14 +251,21 @@ struct MnkPly {
 };
 
 // env/torch_vector_mnk_env.py:60-84 for one env.
-template <int NW, int CN, int CK>
+// TRUSTED: the action comes from our own legal-move sampler (always in [0, C)), so the range
+// check -- a divergent branch around the whole ply -- is compiled out.
+template <int NW, int CN, int CK, bool TRUSTED = false>
 __device__ __forceinline__ MnkPly env_play(const MnkGeom& g, MnkEnv<NW>& e, int64_t action, bool strict) {
   MnkPly out;
   out.win = false; out.done = false; out.err = 0;
   const int C = g.C;
-  const int64_t a64 = action < 0 ? action + C : action;  // torch indexing wraps negatives (:68)
-  if (a64 < 0 || a64 >= C) { out.err = 1; return out; }
-  const uint32_t a = (uint32_t)a64;
+  uint32_t a;
+  if (TRUSTED) {
+    a = (uint32_t)action;
+  } else {
+    const int64_t a64 = action < 0 ? action + C : action;  // torch indexing wraps negatives (:68)
+    if (a64 < 0 || a64 >= C) { out.err = 1; return out; }
+    a = (uint32_t)a64;
+  }
   const uint32_t bit = a + (CN ? a / (uint32_t)CN : mnk_div(a, g.magic_n));  // row*(n+1) + col
   const int wsel = (int)(bit >> 5);
   const uint32_t one = 1u << (bit & 31u);

@@ -223,66 +223,90 @@ k_sample_legal(MnkGeom g, const uint64_t* planes, int64_t N, uint64_t seed, uint
 // ------------------------------------------------------------------ fused random rollout
 // T plies per env in one launch; state lives in registers, HBM sees one load and one
 // store of the state per launch plus the 36-byte (9x9) record of every ply.
-// Wave-level bookkeeping: finished games are counted with ballot + popcount (one scalar
-// add per wave and ply) and folded into the global counters by one lane at the end.
-template <int NW, int CN, int CK>
+// The loop is laid out for a wave that is alone on its SIMD (65 536 envs = 1024 waves =
+// one per SIMD): no divergent branch, per-lane bookkeeping instead of per-ply ballots
+// (scalar round trips), four plies per Philox block with the word picked at compile time.
+template <int NW, int CN, int CK, bool RECORD>
+struct RolloutLane {
+  static constexpr bool EXACT = CN != 0;
+  const MnkGeom& g;
+  MnkEnv<NW> e;
+  int64_t N, i;
+  uint64_t* rec_planes;
+  uint32_t* rec_meta;
+  uint32_t acc_done_draw = 0;    // finished games | draws << 16   (T <= 65535 per launch)
+  uint32_t acc_black_white = 0;  // black wins | white wins << 16
+  uint32_t len_sum = 0;
+
+  __device__ __forceinline__ RolloutLane(const MnkGeom& g_) : g(g_) {}
+
+  __device__ __forceinline__ void ply(int t, uint32_t x) {
+    if (RECORD) {
+      uint64_t* rp = rec_planes + (int64_t)t * 2 * g.W * N;
+      plane_store<NW, EXACT>(e.p[0], rp, N, g.W, i);
+      plane_store<NW, EXACT>(e.p[1], rp + (int64_t)g.W * N, N, g.W, i);
+    }
+    const uint32_t side = e.meta & 1u;
+    const int a = env_pick_legal<NW, CN>(g, e, x);
+    const MnkPly p = env_play<NW, CN, CK, true>(g, e, a, false);
+    const uint32_t win = p.win ? 1u : 0u, done = p.done ? 1u : 0u;
+    if (RECORD)
+      rec_meta[(int64_t)t * N + i] = (uint32_t)a | (win << MNK_REC_REWARD_SHIFT) | (done << MNK_REC_DONE_BIT) |
+                                     (side << MNK_REC_SIDE_BIT);
+    acc_done_draw += done + ((done & ~win) << 16);
+    acc_black_white += (win & ~side) + ((win & side) << 16);
+    len_sum += p.done ? (e.meta >> 1) : 0u;
+    if (p.done) env_clear<NW>(e);  // env.reset(nonzero(done)) :34-44
+  }
+};
+
+template <int NW, int CN, int CK, bool RECORD>
 __global__ void __launch_bounds__(64)
 k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed, uint64_t step0,
                  int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, unsigned long long* stats) {
   // one full wave of 64 envs per workgroup: half-filled waves were measured and are slower
-  // (gfx950 does not skip the idle half of a wave64), see DESIGN.md section 5
+  // (gfx950 does not skip the idle half of a wave64), see DESIGN.md
+  __shared__ unsigned int lds_stats[MNK_STATS_COUNTERS];
+  if (threadIdx.x < MNK_STATS_COUNTERS) lds_stats[threadIdx.x] = 0u;
+  __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < N;
-  const int64_t ii = live ? i : N - 1;  // idle lanes shadow the last env, never store
-  MnkEnv<NW> e;
-  env_load<NW>(e, planes, meta, N, g.W, ii);
-  const uint64_t env = (uint64_t)(env_id0 + ii);
-  unsigned long long n_done = 0, n_black = 0, n_white = 0, n_draw = 0;
-  uint32_t len_sum = 0;
-  Philox4 blk = mnk_rng_block(seed, env, step0 >> 2, MNK_STREAM_MOVE);
-  for (int t = 0; t < T; ++t) {
-    const uint64_t step = step0 + (uint64_t)t;
-    if (t > 0 && (step & 3) == 0) blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
-    const uint32_t x = philox_word(blk, (uint32_t)(step & 3));
-    if (rec_planes && live) {
-      uint64_t* rp = rec_planes + (int64_t)t * 2 * g.W * N;
-      plane_store<NW>(e.p[0], rp, N, g.W, i);
-      plane_store<NW>(e.p[1], rp + (int64_t)g.W * N, N, g.W, i);
+  if (i < N) {
+    RolloutLane<NW, CN, CK, RECORD> L(g);
+    L.N = N; L.i = i; L.rec_planes = rec_planes; L.rec_meta = rec_meta;
+    env_load<NW, L.EXACT>(L.e, planes, meta, N, g.W, i);
+    const uint64_t env = (uint64_t)(env_id0 + i);
+    int t = 0;
+    uint64_t step = step0;
+    if (step & 3) {  // head: finish the Philox block the previous launch stopped in
+      const Philox4 blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
+      for (; t < T && (step & 3); ++t, ++step) L.ply(t, philox_word(blk, (uint32_t)(step & 3)));
     }
-    const uint32_t side = e.meta & 1u;
-    const int a = env_pick_legal<NW, CN>(g, e, x);
-    const MnkPly ply = env_play<NW, CN, CK>(g, e, a, false);
-    if (rec_meta && live)
-      rec_meta[(int64_t)t * N + i] = (uint32_t)a | ((ply.win ? 1u : 0u) << MNK_REC_REWARD_SHIFT) |
-                                     ((ply.done ? 1u : 0u) << MNK_REC_DONE_BIT) | (side << MNK_REC_SIDE_BIT);
-    const bool fin = ply.done && live;
-    n_done += __popcll(__ballot(fin));
-    n_black += __popcll(__ballot(fin && ply.win && side == 0));
-    n_white += __popcll(__ballot(fin && ply.win && side == 1));
-    n_draw += __popcll(__ballot(fin && !ply.win));
-    if (fin) len_sum += e.meta >> 1;
-    if (ply.done) env_clear<NW>(e);  // env.reset(nonzero(done)) :34-44
-  }
-  if (live) env_store<NW>(e, planes, meta, N, g.W, i);
-  if (stats) {
-    // sum of the lanes' episode lengths through one LDS word (only the lanes still running take part)
-    __shared__ unsigned int lds_len;
-    if (threadIdx.x == 0) lds_len = 0u;
-    __syncthreads();
-    if (len_sum) atomicAdd(&lds_len, len_sum);
-    __syncthreads();
-    const unsigned long long ls = lds_len;
-    if ((threadIdx.x & 63) == 0) {
-      // one atomic per counter per wave would serialise thousands of adds on five addresses
-      // (~11 ns each); the counters are replicated over MNK_STATS_REPLICAS cache lines instead
-      unsigned long long* slot = stats + (size_t)(blockIdx.x % MNK_STATS_REPLICAS) * MNK_STATS_STRIDE;
-      if (n_done) atomicAdd(&slot[0], n_done);
-      if (n_black) atomicAdd(&slot[1], n_black);
-      if (n_white) atomicAdd(&slot[2], n_white);
-      if (n_draw) atomicAdd(&slot[3], n_draw);
-      if (ls) atomicAdd(&slot[4], ls);
+    for (; t + 4 <= T; t += 4, step += 4) {
+      const Philox4 blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
+      L.ply(t, blk.v[0]);
+      L.ply(t + 1, blk.v[1]);
+      L.ply(t + 2, blk.v[2]);
+      L.ply(t + 3, blk.v[3]);
+    }
+    if (t < T) {
+      const Philox4 blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
+      for (uint32_t j = 0; t < T; ++t, ++j) L.ply(t, philox_word(blk, j));
+    }
+    env_store<NW, L.EXACT>(L.e, planes, meta, N, g.W, i);
+    if (stats) {
+      if (L.acc_done_draw & 0xFFFFu) atomicAdd(&lds_stats[0], L.acc_done_draw & 0xFFFFu);
+      if (L.acc_black_white & 0xFFFFu) atomicAdd(&lds_stats[1], L.acc_black_white & 0xFFFFu);
+      if (L.acc_black_white >> 16) atomicAdd(&lds_stats[2], L.acc_black_white >> 16);
+      if (L.acc_done_draw >> 16) atomicAdd(&lds_stats[3], L.acc_done_draw >> 16);
+      if (L.len_sum) atomicAdd(&lds_stats[4], L.len_sum);
     }
   }
+  __syncthreads();
+  // one global atomic per counter per wave, spread over MNK_STATS_REPLICAS cache lines: thousands
+  // of adds on five addresses would serialise at ~11 ns each (measured: 56 us per launch)
+  if (stats && threadIdx.x < MNK_STATS_COUNTERS && lds_stats[threadIdx.x])
+    atomicAdd(&stats[(size_t)(blockIdx.x % MNK_STATS_REPLICAS) * MNK_STATS_STRIDE + threadIdx.x],
+              (unsigned long long)lds_stats[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------ fused self-play step
@@ -423,7 +447,7 @@ k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, c
     SpAgent a = sp_agent_half<NW, CN, CK>(g, e, actions[i], pend, side, forced_side, seed, step, env, i, err);
     if (a.need_opp) {
       const int oa = env_pick_legal<NW, CN>(g, e, mnk_rand_u32(seed, env, step, MNK_STREAM_OPP));
-      const MnkPly ply = env_play<NW, CN, CK>(g, e, oa, false);
+      const MnkPly ply = env_play<NW, CN, CK, true>(g, e, oa, false);
       if (!a.was_reset) {
         a.reward -= ply.win ? 1.0f : 0.0f;
         a.term = ply.done;
@@ -721,13 +745,18 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   MnkGeom g;
   int rc = mnk_check_geom(m, n, k, &g);
   if (rc != MNK_OK) return rc;
-  if (!planes || !meta || N < 0 || T < 0) return MNK_EINVAL;
+  if (!planes || !meta || N < 0 || T < 0 || T > 65535 || (!rec_planes != !rec_meta)) return MNK_EINVAL;
   if (N == 0 || T == 0) return MNK_OK;
   const int B = 64;
   const dim3 grid((unsigned)((N + B - 1) / B));
-  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_rollout_random), grid, dim3(B), 0, (hipStream_t)stream, g, planes, meta,
-                                         N, T, seed, step0, env_id0, rec_planes, rec_meta,
-                                         (unsigned long long*)stats));
+  if (rec_planes && rec_meta)
+    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NW, CN, CK, true>), grid, dim3(B), 0,
+                                       (hipStream_t)stream, g, planes, meta, N, T, seed, step0, env_id0, rec_planes,
+                                       rec_meta, (unsigned long long*)stats));
+  else
+    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NW, CN, CK, false>), grid, dim3(B), 0,
+                                       (hipStream_t)stream, g, planes, meta, N, T, seed, step0, env_id0, nullptr,
+                                       nullptr, (unsigned long long*)stats));
   return mnk_launch_status("rollout_random");
 }
 

@@ -157,6 +157,7 @@ def test_sample_legal_matches_oracle(hip, m, n, k, nenv):
 
 
 @pytest.mark.parametrize("m,n,k,nenv,chunks", [(3, 3, 3, 64, (7, 9, 16)), (9, 9, 5, 333, (64, 31)),
+                                               (3, 3, 3, 3, (30,)), (9, 9, 5, 1, (5, 6, 200)), (5, 6, 4, 129, (61,)),
                                                (4, 6, 3, 100, (40,)), (13, 13, 5, 65, (120,)),
                                                (19, 19, 5, 64, (200,)), (7, 9, 7, 70, (90,))])
 def test_rollout_matches_oracle(hip, m, n, k, nenv, chunks):

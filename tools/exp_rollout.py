@@ -24,11 +24,14 @@ def run(nenv, T, record, launches=20, board=(9, 9, 5)):
           f"{nenv*T/us*1e6:.3e} env-steps/s", flush=True)
 
 if __name__ == "__main__":
-    for lanes in ("64", "32", "16"):
-        os.environ["MNK_ROLLOUT_LANES"] = lanes
-        print("lanes per wave:", lanes)
-        run(65536, 64, True)
-        run(65536, 256, True, launches=8)
-        run(131072, 64, True)
-        run(262144, 64, True)
-        run(32768, 64, True, board=(19, 19, 5))
+    run(65536, 64, True)
+    run(65536, 256, True, launches=8)
+    run(65536, 256, False, launches=8)
+    run(131072, 256, True, launches=8)
+    run(262144, 256, True, launches=8)
+    run(1048576, 64, True, launches=8)
+    run(32768, 256, True, launches=8, board=(19, 19, 5))
+    run(262144, 64, True, board=(19, 19, 5))
+    run(65536, 256, True, launches=8, board=(3, 3, 3))
+    run(65536, 256, True, launches=8, board=(13, 13, 5))
+    run(65536, 256, True, launches=8, board=(7, 9, 7))
