@@ -6,8 +6,10 @@ rollout.  A "step" is one ply on every env of the batch: uniform legal move (Ran
 place stone, 4-direction win scan, reward/done, restart of finished games, packed record
 written to HBM -- executed by the fused kernel ``mnk_rollout_random`` in chunks of
 ``--chunk`` plies per launch.  With --gpus N > 1 the env axis is sharded (65 536 envs per
-rank, global env ids key the RNG) and every chunk's packed records are all-gathered over
-RCCL on a side stream while the next chunk runs.
+rank, global env ids key the RNG) and every chunk is all-gathered over RCCL on a side stream
+while the next chunk runs -- by default as chunk-start state + action log (1 B per env-step at
+9x9, rebuilt into full records on demand by mnk_replay_actions), with --gather records as the
+36 B packed records themselves.
 
     python bench.py                       # 1 GPU, defaults finish in well under a minute
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -45,6 +47,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, host cores): the CPU share of one GPU")
     ap.add_argument("--no-api-path", action="store_true", help="skip the extra per-step-launch measurement")
+    ap.add_argument("--gather", choices=("actions", "records", "none"), default="actions",
+                    help="what ranks all-gather per chunk when --gpus > 1 (ignored on one GPU)")
     return ap.parse_args()
 
 
@@ -127,6 +131,25 @@ def api_path_rate(env, seed, steps=200):
     return steps * n / (time.perf_counter() - t0)
 
 
+def replay_rate(env, roll, chunk, reps=8):
+    """Receiving side of the multi-GPU exchange: rebuild one shard's full records from its
+    chunk-start state + action log (mnk_replay_actions); reported for transparency."""
+    from selfplay.random_rollout import GatheredLogs, replay_shard
+
+    rec = roll.alloc(chunk, log_actions=True)
+    roll.run(chunk, out=rec)
+    logs = GatheredLogs(planes0=rec.planes[0].unsqueeze(0).clone(), meta0=rec.meta0.unsqueeze(0).clone(),
+                        act=rec.act.unsqueeze(0))
+    out = replay_shard(logs, 0, env.m, env.n, env.k)
+    assert torch.equal(out.planes, rec.planes) and torch.equal(out.meta, rec.meta), "replay != records"
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        replay_shard(logs, 0, env.m, env.n, env.k, out=out)
+    torch.cuda.synchronize()
+    return reps * chunk * env.num_envs / (time.perf_counter() - t0)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -139,7 +162,8 @@ def main():
 
     import mnk_hip
     from env.torch_vector_mnk_env import TorchVectorMnkEnv
-    from selfplay.random_rollout import RandomRollout
+    from selfplay.random_rollout import (GatheredLogs, RandomRollout, RolloutRecords, action_log_dtype,
+                                         gather_action_logs, replay_shard)
 
     mnk_hip.load()
     dev = torch.device("cuda", local_rank)
@@ -156,18 +180,25 @@ def main():
     env = TorchVectorMnkEnv(m, n, k, nenv, device=str(dev))
     env.reset()
     roll = RandomRollout(env, seed=args.seed, env_id0=rank * nenv)
-    bufs = [roll.alloc(chunk) for _ in range(2)]
+    mode = args.gather if world > 1 else "none"
+    bufs = [roll.alloc(chunk, log_actions=(mode == "actions")) for _ in range(2)]
     gathered = side = None
-    if world > 1:
+    if mode != "none":
         side = torch.cuda.Stream(dev)
-        gathered = [(torch.empty((world,) + tuple(b.planes.shape), dtype=torch.int64, device=dev),
-                     torch.empty((world,) + tuple(b.meta.shape), dtype=torch.int32, device=dev)) for b in bufs]
+        if mode == "records":
+            gathered = [(torch.empty((world,) + tuple(b.planes.shape), dtype=torch.int64, device=dev),
+                         torch.empty((world,) + tuple(b.meta.shape), dtype=torch.int32, device=dev)) for b in bufs]
+        else:
+            gathered = [GatheredLogs(planes0=torch.empty((world, 2, env.words, nenv), dtype=torch.int64, device=dev),
+                                     meta0=torch.empty((world, nenv), dtype=torch.int32, device=dev),
+                                     act=torch.empty((world, chunk, nenv), dtype=action_log_dtype(env.max_moves),
+                                                     device=dev)) for _ in bufs]
     main_stream = torch.cuda.current_stream(dev)
     gather_done = [None, None]
 
     def run_steps(total):
-        """`total` plies per env: ceil(total/chunk) launches; the records of each chunk are all-gathered
-        on the side stream while the next chunk computes.  Returns the number of launches."""
+        """`total` plies per env: ceil(total/chunk) launches; each chunk is all-gathered on the side
+        stream while the next chunk computes.  Returns the number of launches."""
         launches, done, c = 0, 0, 0
         while done < total:
             t = min(chunk, total - done)
@@ -176,27 +207,31 @@ def main():
                 main_stream.wait_event(gather_done[slot])  # the buffer is free again
             out = bufs[slot]
             if t != chunk:
-                out = type(out)(planes=out.planes[:t], meta=out.meta[:t])
+                out = RolloutRecords(planes=out.planes[:t], meta=out.meta[:t],
+                                     act=None if out.act is None else out.act[:t], meta0=out.meta0)
             roll.run(t, out=out)
             launches += 1
-            if world > 1:
+            if mode != "none":
                 ready = torch.cuda.Event()
                 ready.record(main_stream)
                 with torch.cuda.stream(side):
                     side.wait_event(ready)
-                    if t == chunk:
-                        gp, gm = gathered[slot]
-                    else:  # ragged last chunk: its own (contiguous) landing buffers
-                        gp = torch.empty((world,) + tuple(out.planes.shape), dtype=torch.int64, device=dev)
-                        gm = torch.empty((world,) + tuple(out.meta.shape), dtype=torch.int32, device=dev)
-                    dist.all_gather_into_tensor(gp, out.planes)
-                    dist.all_gather_into_tensor(gm, out.meta)
+                    if mode == "actions":
+                        gather_action_logs(out, out=gathered[slot] if t == chunk else None)
+                    else:
+                        if t == chunk:
+                            gp, gm = gathered[slot]
+                        else:  # ragged last chunk: its own (contiguous) landing buffers
+                            gp = torch.empty((world,) + tuple(out.planes.shape), dtype=torch.int64, device=dev)
+                            gm = torch.empty((world,) + tuple(out.meta.shape), dtype=torch.int32, device=dev)
+                        dist.all_gather_into_tensor(gp.view(-1), out.planes.view(-1))
+                        dist.all_gather_into_tensor(gm.view(-1), out.meta.view(-1))
                     ev = torch.cuda.Event()
                     ev.record(side)
                     gather_done[slot] = ev
             done += t
             c += 1
-        if world > 1:
+        if mode != "none":
             main_stream.wait_stream(side)
         return launches
 
@@ -243,8 +278,9 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{m}x{n}x{k}, {nenv} envs/GPU, fused random rollout (sample+step+win-scan+reset+record), "
-                        f"{chunk} plies/launch" + (f", records all-gathered over RCCL across {world} GPUs" if world > 1 else ""),
-            "envs_per_gpu": nenv, "chunk": chunk, "board": args.board, "seed": args.seed,
+                        f"{chunk} plies/launch" + (f", per-chunk RCCL all-gather of {mode} across {world} GPUs"
+                                                   if mode != "none" else ""),
+            "envs_per_gpu": nenv, "chunk": chunk, "board": args.board, "seed": args.seed, "gather": mode,
         },
         "roofline": {
             "bound": "hbm",
@@ -266,6 +302,7 @@ def main():
                                 "draw_rate": stats[3] / max(stats[0], 1)}
         if world == 1 and not args.no_api_path:
             out["api_path_env_steps_per_s"] = api_path_rate(env, args.seed)
+            out["replay_env_steps_per_s"] = replay_rate(env, roll, chunk)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(env, args.cpu_seconds, args.cpu_threads)
         else:

@@ -164,10 +164,22 @@ int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m,
  * rec_planes u64[T][2][W][N]: absolute planes BEFORE each ply; rec_meta u32[T][N]: MNK_REC_* word;
  * stats (optional) int64[MNK_STATS_REPLICAS][MNK_STATS_STRIDE] += {episodes finished, black wins,
  * white wins, draws, sum of episode lengths} spread over the replicas (sum the rows to read a counter).
- * rec_planes / rec_meta may be NULL (state-only rollout). */
+ * rec_planes / rec_meta may be NULL together (state-only rollout); act_log may be NULL. */
 int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, int T,
                        uint64_t seed, uint64_t step0, int64_t env_id0,
-                       uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats, void* stream);
+                       uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
+                       void* act_log, int act_bytes, void* stream);
+
+/* The multi-GPU exchange format.  A shard's rollout is a pure function of its chunk-start state and
+ * its actions, so the action log -- act_log u8[T][N] (act_bytes 1, boards with <= 256 cells) or
+ * u16[T][N] (act_bytes 2), optionally written by mnk_rollout_random -- is what ranks all-gather
+ * (1-2 B per env-step instead of the 36 B packed record or the reference's 750 B RolloutBuffer row).
+ * mnk_replay_actions re-plays a log from `planes`/`meta` (updated in place, like the rollout) and
+ * rebuilds rec_planes / rec_meta bit-identical to what the sender recorded (both may be NULL to only
+ * advance the state).  An action >= m*n in the log is reported through err. */
+int mnk_replay_actions(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, int T,
+                       const void* act_log, int act_bytes, uint64_t* rec_planes, uint32_t* rec_meta,
+                       int32_t* err, void* stream);
 
 /* Unpack gathered records into the reference's RolloutBuffer layout (alg/rollout_buffer.py:14-44):
  * obs f32[T][N][2][m][n] from the mover's point of view, masks u8[T][N][C], actions i64[T][N],

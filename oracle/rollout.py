@@ -73,6 +73,23 @@ def random_rollout(env, seed: int, step0: int, steps: int, env_id0: int = 0):
     return planes, meta, stats
 
 
+def replay_actions(env, actions):
+    """Replays an action log on ``env`` (an OracleVectorEnv in its chunk-start state): the records the
+    fused rollout would have written for those actions -- what ``mnk_replay_actions`` must rebuild.
+    actions: int array [T, N].  Returns (rec_planes u64[T,2,W,N], rec_meta u32[T,N])."""
+    m, n = env.m, env.n
+    rec_planes, rec_meta = [], []
+    for act in np.asarray(actions, dtype=np.int64):
+        side = env.current_player.numpy().copy()
+        rec_planes.append(pack_boards(env.boards.numpy(), m, n))
+        _, rew, done = env.step(torch.from_numpy(act))
+        done_np = done.numpy()
+        rec_meta.append(encode_record(act, rew.numpy().astype(np.int64), done_np, side))
+        if done_np.any():
+            env.reset(torch.from_numpy(np.nonzero(done_np)[0]))
+    return np.stack(rec_planes), np.stack(rec_meta)
+
+
 def gae(rewards, values, dones, last_values, gamma=0.99, lam=0.95):
     """f32 restatement of rollout_buffer.py:60-80.  Inputs are [T, N] (+ [N]); returns (adv, ret)."""
     rewards = np.asarray(rewards, dtype=np.float32)

@@ -234,6 +234,8 @@ struct RolloutLane {
   int64_t N, i;
   uint64_t* rec_planes;
   uint32_t* rec_meta;
+  uint8_t* act8 = nullptr;    // optional action log, one byte per ply (boards with <= 256 cells)
+  uint16_t* act16 = nullptr;  // ... or two bytes per ply
   uint32_t acc_done_draw = 0;    // finished games | draws << 16   (T <= 65535 per launch)
   uint32_t acc_black_white = 0;  // black wins | white wins << 16
   uint32_t len_sum = 0;
@@ -241,13 +243,20 @@ struct RolloutLane {
   __device__ __forceinline__ RolloutLane(const MnkGeom& g_) : g(g_) {}
 
   __device__ __forceinline__ void ply(int t, uint32_t x) {
+    const int a = env_pick_legal<NW, CN>(g, e, x);
+    if (act8) act8[(int64_t)t * N + i] = (uint8_t)a;
+    if (act16) act16[(int64_t)t * N + i] = (uint16_t)a;
+    ply_action(t, a);
+  }
+
+  // one ply with a known-good action (from the sampler, or from an action log the sampler wrote)
+  __device__ __forceinline__ void ply_action(int t, int a) {
     if (RECORD) {
       uint64_t* rp = rec_planes + (int64_t)t * 2 * g.W * N;
       plane_store<NW, EXACT>(e.p[0], rp, N, g.W, i);
       plane_store<NW, EXACT>(e.p[1], rp + (int64_t)g.W * N, N, g.W, i);
     }
     const uint32_t side = e.meta & 1u;
-    const int a = env_pick_legal<NW, CN>(g, e, x);
     const MnkPly p = env_play<NW, CN, CK, true>(g, e, a, false);
     const uint32_t win = p.win ? 1u : 0u, done = p.done ? 1u : 0u;
     if (RECORD)
@@ -263,7 +272,8 @@ struct RolloutLane {
 template <int NW, int CN, int CK, bool RECORD>
 __global__ void __launch_bounds__(64)
 k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed, uint64_t step0,
-                 int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, unsigned long long* stats) {
+                 int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, unsigned long long* stats,
+                 void* act_log, int act_bytes) {
   // one full wave of 64 envs per workgroup: half-filled waves were measured and are slower
   // (gfx950 does not skip the idle half of a wave64), see DESIGN.md
   __shared__ unsigned int lds_stats[MNK_STATS_COUNTERS];
@@ -273,6 +283,8 @@ k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, 
   if (i < N) {
     RolloutLane<NW, CN, CK, RECORD> L(g);
     L.N = N; L.i = i; L.rec_planes = rec_planes; L.rec_meta = rec_meta;
+    if (act_bytes == 1) L.act8 = (uint8_t*)act_log;
+    if (act_bytes == 2) L.act16 = (uint16_t*)act_log;
     env_load<NW, L.EXACT>(L.e, planes, meta, N, g.W, i);
     const uint64_t env = (uint64_t)(env_id0 + i);
     int t = 0;
@@ -307,6 +319,31 @@ k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, 
   if (stats && threadIdx.x < MNK_STATS_COUNTERS && lds_stats[threadIdx.x])
     atomicAdd(&stats[(size_t)(blockIdx.x % MNK_STATS_REPLICAS) * MNK_STATS_STRIDE + threadIdx.x],
               (unsigned long long)lds_stats[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------ replay of an action log
+// The receiving side of the multi-GPU exchange: a shard's rollout is fully determined by its
+// chunk-start state and its action log (1-2 bytes per ply), so that is what crosses xGMI; this
+// kernel re-plays the log and rebuilds the full packed records, bit-identical to the sender's.
+template <int NW, int CN, int CK, bool RECORD>
+__global__ void __launch_bounds__(64)
+k_replay_actions(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, const void* act_log, int act_bytes,
+                 uint64_t* rec_planes, uint32_t* rec_meta, int32_t* err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  RolloutLane<NW, CN, CK, RECORD> L(g);
+  L.N = N; L.i = i; L.rec_planes = rec_planes; L.rec_meta = rec_meta;
+  env_load<NW, L.EXACT>(L.e, planes, meta, N, g.W, i);
+  const uint8_t* a8 = (const uint8_t*)act_log;
+  const uint16_t* a16 = (const uint16_t*)act_log;
+  bool bad = false;
+  for (int t = 0; t < T; ++t) {
+    int a = act_bytes == 1 ? (int)a8[(int64_t)t * N + i] : (int)a16[(int64_t)t * N + i];
+    if (a >= g.C) { bad = true; a = 0; }  // a log we did not write: flag it, keep the wave in step
+    L.ply_action(t, a);
+  }
+  if (bad) mnk_report(err, MNK_ERR_ACTION_RANGE, i);
+  env_store<NW, L.EXACT>(L.e, planes, meta, N, g.W, i);
 }
 
 // ------------------------------------------------------------------ fused self-play step
@@ -741,23 +778,46 @@ int mnk_sample_legal(const uint64_t* planes, int64_t N, int m, int n, uint64_t s
 
 int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, int T, uint64_t seed,
                        uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
-                       void* stream) {
+                       void* act_log, int act_bytes, void* stream) {
   MnkGeom g;
   int rc = mnk_check_geom(m, n, k, &g);
   if (rc != MNK_OK) return rc;
   if (!planes || !meta || N < 0 || T < 0 || T > 65535 || (!rec_planes != !rec_meta)) return MNK_EINVAL;
+  if (act_log && !(act_bytes == 2 || (act_bytes == 1 && g.C <= 256))) return MNK_EINVAL;
+  if (!act_log) act_bytes = 0;
   if (N == 0 || T == 0) return MNK_OK;
   const int B = 64;
   const dim3 grid((unsigned)((N + B - 1) / B));
   if (rec_planes && rec_meta)
     MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NW, CN, CK, true>), grid, dim3(B), 0,
                                        (hipStream_t)stream, g, planes, meta, N, T, seed, step0, env_id0, rec_planes,
-                                       rec_meta, (unsigned long long*)stats));
+                                       rec_meta, (unsigned long long*)stats, act_log, act_bytes));
   else
     MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NW, CN, CK, false>), grid, dim3(B), 0,
                                        (hipStream_t)stream, g, planes, meta, N, T, seed, step0, env_id0, nullptr,
-                                       nullptr, (unsigned long long*)stats));
+                                       nullptr, (unsigned long long*)stats, act_log, act_bytes));
   return mnk_launch_status("rollout_random");
+}
+
+int mnk_replay_actions(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, int T, const void* act_log,
+                       int act_bytes, uint64_t* rec_planes, uint32_t* rec_meta, int32_t* err, void* stream) {
+  MnkGeom g;
+  int rc = mnk_check_geom(m, n, k, &g);
+  if (rc != MNK_OK) return rc;
+  if (!planes || !meta || !act_log || N < 0 || T < 0 || (!rec_planes != !rec_meta)) return MNK_EINVAL;
+  if (!(act_bytes == 2 || (act_bytes == 1 && g.C <= 256))) return MNK_EINVAL;
+  if (N == 0 || T == 0) return MNK_OK;
+  const int B = 64;
+  const dim3 grid((unsigned)((N + B - 1) / B));
+  if (rec_planes && rec_meta)
+    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_replay_actions<NW, CN, CK, true>), grid, dim3(B), 0,
+                                       (hipStream_t)stream, g, planes, meta, N, T, act_log, act_bytes, rec_planes,
+                                       rec_meta, err));
+  else
+    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_replay_actions<NW, CN, CK, false>), grid, dim3(B), 0,
+                                       (hipStream_t)stream, g, planes, meta, N, T, act_log, act_bytes, nullptr,
+                                       nullptr, err));
+  return mnk_launch_status("replay_actions");
 }
 
 int mnk_selfplay_pre(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const int64_t* actions,

@@ -12,8 +12,13 @@ HBM is the packed record of each ply:
 
 Envs are independent, so a node shards them by contiguous blocks: rank r owns global
 env ids [r*N, (r+1)*N) and the Philox key uses the global id, which makes the records
-independent of the number of GPUs.  ``gather()`` is the one exchange step: an
-all-gather of the packed records (RCCL over xGMI when the process group is ``nccl``).
+independent of the number of GPUs.  There is one exchange step, an all-gather over the
+process group (RCCL over xGMI when the backend is ``nccl``), in one of two formats:
+
+  * ``gather_records``      the packed records themselves (36 B per env-step at 9x9);
+  * ``gather_action_logs``  the chunk-start state plus the action log (1-2 B per env-step):
+                            a rollout is a pure function of those, and ``replay_shard`` rebuilds
+                            any shard's full records bit-identically on the receiving GPU.
 """
 from dataclasses import dataclass
 from typing import Optional
@@ -27,6 +32,8 @@ import mnk_hip
 class RolloutRecords:
     planes: torch.Tensor  # int64 (u64 bits) [T, 2, W, N]
     meta: torch.Tensor    # int32 (u32 bits) [T, N]
+    act: Optional[torch.Tensor] = None    # action log uint8 / int16 [T, N] (when logging was on)
+    meta0: Optional[torch.Tensor] = None  # env meta words at the start of the chunk, int32 [N]
 
     @property
     def steps(self) -> int:
@@ -65,12 +72,16 @@ class RandomRollout:
         """int64[5]: episodes finished, black wins, white wins, draws, sum of finished-episode lengths"""
         return self._stats.sum(dim=0)[:mnk_hip.STATS_COUNTERS]
 
-    def alloc(self, steps: int) -> RolloutRecords:
+    def alloc(self, steps: int, log_actions: bool = False) -> RolloutRecords:
         env = self.env
-        return RolloutRecords(
+        rec = RolloutRecords(
             planes=torch.empty((steps, 2, env.words, env.num_envs), dtype=torch.int64, device=env._dev),
             meta=torch.empty((steps, env.num_envs), dtype=torch.int32, device=env._dev),
         )
+        if log_actions:
+            rec.act = torch.empty((steps, env.num_envs), dtype=action_log_dtype(env.max_moves), device=env._dev)
+            rec.meta0 = torch.empty(env.num_envs, dtype=torch.int32, device=env._dev)
+        return rec
 
     def run(self, steps: int, out: Optional[RolloutRecords] = None, record: bool = True) -> Optional[RolloutRecords]:
         """Plays ``steps`` random plies on every env (finished games restart in place).
@@ -78,15 +89,73 @@ class RandomRollout:
         env = self.env
         if record and out is None:
             out = self.alloc(steps)
+        act = None
         if record:
             assert out.meta.shape == (steps, env.num_envs) and out.planes.shape[0] == steps
+            act = out.act
+            if out.meta0 is not None:
+                out.meta0.copy_(env._meta)  # with planes[0] this is the chunk-start state a replay needs
         if env.num_envs and steps:
             mnk_hip.call("mnk_rollout_random", mnk_hip.ptr(env._planes), mnk_hip.ptr(env._meta), env.num_envs,
                          env.m, env.n, env.k, steps, self.seed, self.step, self.env_id0,
                          mnk_hip.ptr(out.planes) if record else None, mnk_hip.ptr(out.meta) if record else None,
-                         mnk_hip.ptr(self._stats), env._stream())
+                         mnk_hip.ptr(self._stats), mnk_hip.ptr(act), act.element_size() if act is not None else 0,
+                         env._stream())
         self.step += steps
         return out if record else None
+
+
+def action_log_dtype(num_actions: int):
+    """one byte per ply while the board has at most 256 cells, two beyond"""
+    return torch.uint8 if num_actions <= 256 else torch.int16
+
+
+@dataclass
+class GatheredLogs:
+    """What ``gather_action_logs`` leaves on every rank: per shard r the chunk-start state and the log."""
+    planes0: torch.Tensor  # int64 [world, 2, W, N]
+    meta0: torch.Tensor    # int32 [world, N]
+    act: torch.Tensor      # uint8 / int16 [world, T, N]
+
+
+def gather_action_logs(rec: RolloutRecords, group=None, out: Optional[GatheredLogs] = None) -> GatheredLogs:
+    """All-gather of (chunk-start state, action log): 1-2 bytes per env-step on the wire."""
+    import torch.distributed as dist
+
+    assert rec.act is not None and rec.meta0 is not None, "run the rollout with alloc(..., log_actions=True)"
+    world = dist.get_world_size(group)
+    t, two, w, n = rec.planes.shape
+    dev = rec.planes.device
+    if out is None:
+        out = GatheredLogs(planes0=torch.empty((world, two, w, n), dtype=torch.int64, device=dev),
+                           meta0=torch.empty((world, n), dtype=torch.int32, device=dev),
+                           act=torch.empty((world, t, n), dtype=rec.act.dtype, device=dev))
+    dist.all_gather_into_tensor(out.planes0.view(-1), rec.planes[0].reshape(-1), group=group)
+    dist.all_gather_into_tensor(out.meta0.view(-1), rec.meta0.view(-1), group=group)
+    dist.all_gather_into_tensor(out.act.view(-1), rec.act.view(-1), group=group)
+    return out
+
+
+def replay_shard(logs: GatheredLogs, shard: int, m: int, n: int, k: int, err: Optional[torch.Tensor] = None,
+                 out: Optional[RolloutRecords] = None) -> RolloutRecords:
+    """Rebuilds shard ``shard``'s full packed records from its gathered state + action log
+    (``mnk_replay_actions``, one launch); bit-identical to what the owning rank recorded."""
+    act = logs.act[shard]
+    t, nenv = act.shape
+    dev = act.device
+    planes = logs.planes0[shard].clone()
+    meta = logs.meta0[shard].clone()
+    words = planes.shape[1]
+    if out is None:
+        out = RolloutRecords(planes=torch.empty((t, 2, words, nenv), dtype=torch.int64, device=dev),
+                             meta=torch.empty((t, nenv), dtype=torch.int32, device=dev))
+    if err is None:
+        err = torch.zeros(2, dtype=torch.int32, device=dev)
+    if t and nenv:
+        mnk_hip.call("mnk_replay_actions", mnk_hip.ptr(planes), mnk_hip.ptr(meta), nenv, m, n, k, t,
+                     mnk_hip.ptr(act), act.element_size(), mnk_hip.ptr(out.planes), mnk_hip.ptr(out.meta),
+                     mnk_hip.ptr(err), mnk_hip.stream_ptr(dev))
+    return out
 
 
 def gather_records(rec: RolloutRecords, group=None) -> RolloutRecords:
@@ -105,8 +174,9 @@ def gather_records(rec: RolloutRecords, group=None) -> RolloutRecords:
     t, two, w, n = rec.planes.shape
     planes_all = torch.empty((world, t, two, w, n), dtype=rec.planes.dtype, device=rec.planes.device)
     meta_all = torch.empty((world, t, n), dtype=rec.meta.dtype, device=rec.meta.device)
-    dist.all_gather_into_tensor(planes_all, rec.planes.contiguous(), group=group)
-    dist.all_gather_into_tensor(meta_all, rec.meta.contiguous(), group=group)
+    # flat views: the concatenated form every backend accepts (gloo rejects the stacked shape)
+    dist.all_gather_into_tensor(planes_all.view(-1), rec.planes.contiguous().view(-1), group=group)
+    dist.all_gather_into_tensor(meta_all.view(-1), rec.meta.contiguous().view(-1), group=group)
     planes = planes_all.permute(1, 2, 3, 0, 4).reshape(t, two, w, world * n)
     meta = meta_all.permute(1, 0, 2).reshape(t, world * n)
     return RolloutRecords(planes=planes.contiguous(), meta=meta.contiguous())
