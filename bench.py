@@ -32,6 +32,13 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
+# HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
+# (FETCH_SIZE x 1024 x 2 [gfx950 correction] + WRITE_SIZE x 1024), keyed by (board, envs/GPU, chunk).
+# bench.py cannot run rocprofv3 on itself; configurations without a committed profile report null.
+PMC_TRAFFIC = {
+    ("9x9x5", 65536, 256): (608.94e6, "profiles/r01_rollout_9x9x5.md"),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -47,6 +54,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, host cores): the CPU share of one GPU")
     ap.add_argument("--no-api-path", action="store_true", help="skip the extra per-step-launch measurement")
+    ap.add_argument("--backend", default="nccl", help="process-group backend; nccl = RCCL.  gloo is for rehearsing "
+                    "the multi-rank path on a one-GPU box (all ranks then share device 0)")
     ap.add_argument("--gather", choices=("actions", "records", "none"), default="actions",
                     help="what ranks all-gather per chunk when --gpus > 1 (ignored on one GPU)")
     return ap.parse_args()
@@ -166,14 +175,17 @@ def main():
                                          gather_action_logs, replay_shard)
 
     mnk_hip.load()
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     m, n, k = (int(v) for v in args.board.split("x"))
     nenv, chunk = args.envs, args.chunk
@@ -195,6 +207,9 @@ def main():
                                                      device=dev)) for _ in bufs]
     main_stream = torch.cuda.current_stream(dev)
     gather_done = [None, None]
+    kernel_events = []  # (start, end) HIP events around every rollout launch of the timed region
+
+    timing = [False]
 
     def run_steps(total):
         """`total` plies per env: ceil(total/chunk) launches; each chunk is all-gathered on the side
@@ -209,7 +224,13 @@ def main():
             if t != chunk:
                 out = RolloutRecords(planes=out.planes[:t], meta=out.meta[:t],
                                      act=None if out.act is None else out.act[:t], meta0=out.meta0)
+            if timing[0]:
+                ks, ke = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ks.record(main_stream)
             roll.run(t, out=out)
+            if timing[0]:
+                ke.record(main_stream)
+                kernel_events.append((ks, ke))
             launches += 1
             if mode != "none":
                 ready = torch.cuda.Event()
@@ -242,14 +263,13 @@ def main():
 
     run_steps(args.warmup)
     barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    timing[0] = True
     t0 = time.perf_counter()
-    e0.record(main_stream)
     launches = run_steps(args.steps)
-    e1.record(main_stream)
     barrier()
     dt = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1)
+    # time spent inside the rollout kernel only (HIP events on its stream, bracketing each launch)
+    dev_ms = sum(a.elapsed_time(b) for a, b in kernel_events)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -288,7 +308,10 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": PMC_TRAFFIC.get((args.board, nenv, chunk), (None, None))[0],
+            "traffic_unit": "bytes per launch",
+            "traffic_source": PMC_TRAFFIC.get((args.board, nenv, chunk), (None, None))[1],
+            "alg_bytes_per_launch": alg_bytes,
             "kernel": "k_rollout_random",
             "launches": launches,
             "avg_launch_us": launch_s * 1e6,
