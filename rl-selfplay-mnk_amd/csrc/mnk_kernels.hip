@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/mnk_hip.h"
@@ -49,6 +50,16 @@ static int mnk_check_geom(int m, int n, int k, MnkGeom* g) {
   return MNK_OK;
 }
 
+// kernels that never look at k (observe, samplers, unpack): hand the dispatcher the k of the
+// specialised variant of that board width so they take the compile-time-geometry path too
+static int mnk_geom_any_k(int m, int n, MnkGeom* g) {
+  int rc = mnk_check_geom(m, n, 1, g);
+  if (rc != MNK_OK) return rc;
+  if (n == 3) g->k = 3;
+  if (n == 9 || n == 13 || n == 15 || n == 19) g->k = 5;
+  return MNK_OK;
+}
+
 static int mnk_launch_status(const char* what) {
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) return MNK_OK;
@@ -61,7 +72,25 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0
 // workgroup size for kernels with a write-out stage (envs per workgroup)
 static int mnk_block_envs(int64_t N) {
   (void)N;
-  return 64;
+  static int cached = 0;
+  if (!cached) {
+    const char* v = getenv("MNK_EMIT_ENVS");
+    int t = v ? atoi(v) : 64;
+    cached = (t == 16 || t == 32 || t == 64) ? t : 64;
+  }
+  return cached;
+}
+
+// threads per workgroup of those kernels: the first 64 lanes play their envs, then all waves of
+// the workgroup sweep its output slab (more waves per SIMD to hide the LDS / store latency)
+static int mnk_block_threads() {
+  static int cached = 0;
+  if (!cached) {
+    const char* v = getenv("MNK_EMIT_THREADS");
+    int t = v ? atoi(v) : 256;
+    cached = (t == 64 || t == 128 || t == 256) ? t : 256;  // kernels are __launch_bounds__(256)
+  }
+  return cached;
 }
 
 // Kernel variants: NW = u32 register words per plane; CN / CK = compile-time board width and
@@ -109,15 +138,15 @@ __global__ void k_reset_mask(uint64_t* planes, uint32_t* meta, int64_t N, int W,
 template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
 k_step_full(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions, float* rewards,
-            uint8_t* dones, uint8_t* legal_mask, float* obs, int32_t* err, uint32_t flags, int vec_ok) {
+            uint8_t* dones, uint8_t* legal_mask, float* obs, int32_t* err, uint32_t flags, int vec_ok, int envs_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int B = blockDim.x, tid = threadIdx.x;
+  const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
   const int64_t env0 = (int64_t)blockIdx.x * B;
   const int64_t i = env0 + tid;
   const bool emit = (legal_mask != nullptr) || (obs != nullptr);
   MnkStage st = mnk_stage_carve(lds_raw, g, B);
-  if (emit) mnk_stage_tables(st, g, B, tid, B);
-  if (i < N) {
+  if (emit) mnk_stage_tables(st, g, B, tid, NT);
+  if (tid < B && i < N) {
     MnkEnv<NW> e;
     env_load<NW>(e, planes, meta, N, g.W, i);
     MnkPly ply = env_play<NW, CN, CK>(g, e, actions[i], (flags & MNK_STEP_STRICT) != 0);
@@ -131,8 +160,8 @@ k_step_full(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_
     __syncthreads();
     const int64_t left = N - env0;
     const int nb = left < B ? (int)left : B;
-    if (obs) mnk_emit_obs(st, g, nb, obs + env0 * 2 * g.C, vec_ok & 1, tid, B);
-    if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, B);
+    if (obs) mnk_emit_obs(st, g, nb, obs + env0 * 2 * g.C, vec_ok & 1, tid, NT);
+    if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, NT);
   }
 }
 
@@ -160,14 +189,14 @@ k_step_subset(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int6
 template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
 k_observe(MnkGeom g, const uint64_t* planes, int64_t N, const int64_t* flip_side, float* obs,
-          uint8_t* legal_mask, int fix_empty, int vec_ok) {
+          uint8_t* legal_mask, int fix_empty, int vec_ok, int envs_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int B = blockDim.x, tid = threadIdx.x;
+  const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
   const int64_t env0 = (int64_t)blockIdx.x * B;
   const int64_t i = env0 + tid;
   MnkStage st = mnk_stage_carve(lds_raw, g, B);
-  mnk_stage_tables(st, g, B, tid, B);
-  if (i < N) {
+  mnk_stage_tables(st, g, B, tid, NT);
+  if (tid < B && i < N) {
     uint32_t p0[NW], p1[NW];
     plane_load<NW>(p0, planes, N, g.W, i);
     plane_load<NW>(p1, planes + (int64_t)g.W * N, N, g.W, i);
@@ -178,8 +207,8 @@ k_observe(MnkGeom g, const uint64_t* planes, int64_t N, const int64_t* flip_side
   __syncthreads();
   const int64_t left = N - env0;
   const int nb = left < B ? (int)left : B;
-  if (obs) mnk_emit_obs(st, g, nb, obs + env0 * 2 * g.C, vec_ok & 1, tid, B);
-  if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, B);
+  if (obs) mnk_emit_obs(st, g, nb, obs + env0 * 2 * g.C, vec_ok & 1, tid, NT);
+  if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, NT);
 }
 
 // dense f32 -> packed; rare path (the writable env.boards view), one lane per env
@@ -381,15 +410,15 @@ __global__ void __launch_bounds__(256)
 k_selfplay_pre(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions,
                const uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
                uint64_t step, int64_t env_id0, float* rewards, uint8_t* terminated, uint8_t* sp_flags,
-               float* opp_obs, uint8_t* opp_mask, int32_t* err, int vec_ok) {
+               float* opp_obs, uint8_t* opp_mask, int32_t* err, int vec_ok, int envs_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int B = blockDim.x, tid = threadIdx.x;
+  const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
   const int64_t env0 = (int64_t)blockIdx.x * B;
   const int64_t i = env0 + tid;
   const bool emit = opp_obs || opp_mask;
   MnkStage st = mnk_stage_carve(lds_raw, g, B);
-  if (emit) mnk_stage_tables(st, g, B, tid, B);
-  if (i < N) {
+  if (emit) mnk_stage_tables(st, g, B, tid, NT);
+  if (tid < B && i < N) {
     MnkEnv<NW> e;
     env_load<NW>(e, planes, meta, N, g.W, i);
     int64_t side = agent_side[i];
@@ -412,8 +441,8 @@ k_selfplay_pre(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int
     __syncthreads();
     const int64_t left = N - env0;
     const int nb = left < B ? (int)left : B;
-    if (opp_obs) mnk_emit_obs(st, g, nb, opp_obs + env0 * 2 * g.C, vec_ok & 1, tid, B);
-    if (opp_mask) mnk_emit_mask(st, g, nb, opp_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, B);
+    if (opp_obs) mnk_emit_obs(st, g, nb, opp_obs + env0 * 2 * g.C, vec_ok & 1, tid, NT);
+    if (opp_mask) mnk_emit_mask(st, g, nb, opp_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, NT);
   }
 }
 
@@ -421,15 +450,15 @@ template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
 k_selfplay_post(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* opp_actions,
                 const uint8_t* sp_flags, const int64_t* agent_side, float* rewards, uint8_t* terminated,
-                uint8_t* pending, float* obs, uint8_t* legal_mask, int32_t* err, int vec_ok) {
+                uint8_t* pending, float* obs, uint8_t* legal_mask, int32_t* err, int vec_ok, int envs_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int B = blockDim.x, tid = threadIdx.x;
+  const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
   const int64_t env0 = (int64_t)blockIdx.x * B;
   const int64_t i = env0 + tid;
   const bool emit = obs || legal_mask;
   MnkStage st = mnk_stage_carve(lds_raw, g, B);
-  if (emit) mnk_stage_tables(st, g, B, tid, B);
-  if (i < N) {
+  if (emit) mnk_stage_tables(st, g, B, tid, NT);
+  if (tid < B && i < N) {
     MnkEnv<NW> e;
     env_load<NW>(e, planes, meta, N, g.W, i);
     const uint32_t f = sp_flags[i];
@@ -456,8 +485,8 @@ k_selfplay_post(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const in
     __syncthreads();
     const int64_t left = N - env0;
     const int nb = left < B ? (int)left : B;
-    if (obs) mnk_emit_obs(st, g, nb, obs + env0 * 2 * g.C, vec_ok & 1, tid, B);
-    if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, B);
+    if (obs) mnk_emit_obs(st, g, nb, obs + env0 * 2 * g.C, vec_ok & 1, tid, NT);
+    if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, NT);
   }
 }
 
@@ -467,15 +496,15 @@ __global__ void __launch_bounds__(256)
 k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions,
                        uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
                        uint64_t step, int64_t env_id0, float* rewards, uint8_t* terminated, float* obs,
-                       uint8_t* legal_mask, int32_t* err, int vec_ok) {
+                       uint8_t* legal_mask, int32_t* err, int vec_ok, int envs_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int B = blockDim.x, tid = threadIdx.x;
+  const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
   const int64_t env0 = (int64_t)blockIdx.x * B;
   const int64_t i = env0 + tid;
   const bool emit = obs || legal_mask;
   MnkStage st = mnk_stage_carve(lds_raw, g, B);
-  if (emit) mnk_stage_tables(st, g, B, tid, B);
-  if (i < N) {
+  if (emit) mnk_stage_tables(st, g, B, tid, NT);
+  if (tid < B && i < N) {
     MnkEnv<NW> e;
     env_load<NW>(e, planes, meta, N, g.W, i);
     int64_t side = agent_side[i];
@@ -504,8 +533,8 @@ k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, c
     __syncthreads();
     const int64_t left = N - env0;
     const int nb = left < B ? (int)left : B;
-    if (obs) mnk_emit_obs(st, g, nb, obs + env0 * 2 * g.C, vec_ok & 1, tid, B);
-    if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, B);
+    if (obs) mnk_emit_obs(st, g, nb, obs + env0 * 2 * g.C, vec_ok & 1, tid, NT);
+    if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, NT);
   }
 }
 
@@ -513,46 +542,51 @@ k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, c
 // alg/architectures/cnn.py:69-79 fused with Categorical.sample (policy.py:46-52).  One wave per
 // row: lanes stride over the C cells, a butterfly (shuffle-xor) argmax picks the winner of the
 // Gumbel-perturbed masked logits; ties go to the lowest cell like torch.argmax.
-__device__ __forceinline__ void wave_argmax(float& v, int& idx) {
+// reductions over one 32-lane half of the wave (a row of logits lives in one half)
+__device__ __forceinline__ void half_argmax(float& v, int& idx) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
+  for (int off = 16; off > 0; off >>= 1) {
     const float ov = __shfl_xor(v, off, 64);
     const int oi = __shfl_xor(idx, off, 64);
     if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
   }
 }
 
-__device__ __forceinline__ float wave_max(float v) {
+__device__ __forceinline__ float half_max(float v) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  for (int off = 16; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
   return v;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
+__device__ __forceinline__ float half_sum(float v) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
 
+// Two rows per wave (one per 32-lane half); a lane takes 4 consecutive cells per sweep, so one
+// Philox block feeds its four Gumbel draws.  -log(-log u) uses the hardware log (v_log_f32): the
+// draw only has to be distributed right (chi-square test), the reported log-prob uses accurate logf.
 __global__ void __launch_bounds__(64)
 k_sample_logits(const float* logits, const uint8_t* mask, int64_t N, int C, uint64_t seed, uint64_t step,
                 int64_t env_id0, int deterministic, int64_t* actions, float* logp) {
-  const int64_t i = blockIdx.x;
-  if (i >= N) return;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x, half = lane >> 5, sub = lane & 31;
+  const int64_t row = (int64_t)blockIdx.x * 2 + half;
+  const bool live = row < N;
+  const int64_t i = live ? row : N - 1;
   const float* lrow = logits + i * C;
   const uint8_t* mrow = mask + i * C;
   const float NEG = -__builtin_huge_valf();
   // does the row have a legal cell at all?  (cnn.py:76-77: all-masked -> zeros -> uniform)
   int any = 0;
-  for (int c = lane; c < C; c += 64) any |= mrow[c];
-  const bool none_legal = __ballot(any != 0) == 0ull;
+  for (int c = sub; c < C; c += 32) any |= mrow[c];
+  const unsigned long long votes = __ballot(any != 0);
+  const bool none_legal = ((uint32_t)(votes >> (32 * half))) == 0u;
   const uint64_t env = (uint64_t)(env_id0 + i);
   const uint32_t CB = (uint32_t)((C + 3) >> 2);
   float best = NEG, vmax = NEG;
   int besti = 0x7fffffff;
-  // lane handles groups of 4 consecutive cells: one Philox block per group
-  for (int c0 = lane * 4; c0 < C; c0 += 256) {
+  for (int c0 = sub * 4; c0 < C; c0 += 128) {
     Philox4 blk;
     if (!deterministic) blk = mnk_rng_block(seed, env, step * (uint64_t)CB + (uint64_t)(c0 >> 2), MNK_STREAM_GUMBEL);
 #pragma unroll
@@ -566,41 +600,41 @@ k_sample_logits(const float* logits, const uint8_t* mask, int64_t N, int C, uint
           float score = l;
           if (!deterministic) {
             const float u = ((float)(blk.v[j] >> 8) + 0.5f) * 5.9604644775390625e-08f;  // (0,1)
-            score = l - logf(-logf(u));
+            score = l - __logf(-__logf(u));
           }
           if (score > best || (score == best && c < besti)) { best = score; besti = c; }
         }
       }
     }
   }
-  wave_argmax(best, besti);
+  half_argmax(best, besti);
   if (logp) {
-    vmax = wave_max(vmax);
+    vmax = half_max(vmax);
     float se = 0.0f;
-    for (int c = lane; c < C; c += 64) {
+    for (int c = sub; c < C; c += 32) {
       const bool legal = none_legal || mrow[c] != 0;
       if (legal) se += expf((none_legal ? 0.0f : lrow[c]) - vmax);
     }
-    se = wave_sum(se);
-    if (lane == 0) logp[i] = (none_legal ? 0.0f : lrow[besti]) - vmax - logf(se);
+    se = half_sum(se);
+    if (sub == 0 && live) logp[row] = (none_legal ? 0.0f : lrow[besti]) - vmax - logf(se);
   }
-  if (lane == 0) actions[i] = besti;
+  if (sub == 0 && live) actions[row] = besti;
 }
 
 // ------------------------------------------------------------------ records -> RolloutBuffer layout
 template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
 k_unpack_records(MnkGeom g, const uint64_t* rec_planes, const uint32_t* rec_meta, int64_t N, float* obs,
-                 uint8_t* masks, int64_t* actions, float* rewards, uint8_t* dones, int vec_ok) {
+                 uint8_t* masks, int64_t* actions, float* rewards, uint8_t* dones, int vec_ok, int envs_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int B = blockDim.x, tid = threadIdx.x;
+  const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
   const int64_t t = blockIdx.y;
   const int64_t env0 = (int64_t)blockIdx.x * B;
   const int64_t i = env0 + tid;
   const bool emit = obs || masks;
   MnkStage st = mnk_stage_carve(lds_raw, g, B);
-  if (emit) mnk_stage_tables(st, g, B, tid, B);
-  if (i < N) {
+  if (emit) mnk_stage_tables(st, g, B, tid, NT);
+  if (tid < B && i < N) {
     const uint32_t mw = rec_meta[t * N + i];
     if (actions) actions[t * N + i] = (int64_t)(mw & MNK_REC_ACTION_MASK);
     if (rewards) rewards[t * N + i] = (float)(int8_t)((mw >> MNK_REC_REWARD_SHIFT) & 0xFFu);
@@ -620,8 +654,8 @@ k_unpack_records(MnkGeom g, const uint64_t* rec_planes, const uint32_t* rec_meta
     const int64_t left = N - env0;
     const int nb = left < B ? (int)left : B;
     const int64_t row0 = t * N + env0;
-    if (obs) mnk_emit_obs(st, g, nb, obs + row0 * 2 * g.C, vec_ok & 1, tid, B);
-    if (masks) mnk_emit_mask(st, g, nb, masks + row0 * g.C, (vec_ok >> 1) & 1, tid, B);
+    if (obs) mnk_emit_obs(st, g, nb, obs + row0 * 2 * g.C, vec_ok & 1, tid, NT);
+    if (masks) mnk_emit_mask(st, g, nb, masks + row0 * g.C, (vec_ok >> 1) & 1, tid, NT);
   }
 }
 
@@ -697,7 +731,7 @@ int mnk_observe(const uint64_t* planes, const uint32_t* meta, int64_t N, int m, 
                 float* obs, uint8_t* legal_mask, int fix_empty_mask, void* stream) {
   (void)meta;
   MnkGeom g;
-  int rc = mnk_check_geom(m, n, 1, &g);
+  int rc = mnk_geom_any_k(m, n, &g);
   if (rc != MNK_OK) return rc;
   if (!planes || N < 0) return MNK_EINVAL;
   if (N == 0 || (!obs && !legal_mask)) return MNK_OK;
@@ -705,8 +739,8 @@ int mnk_observe(const uint64_t* planes, const uint32_t* meta, int64_t N, int m, 
   const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
   const size_t lds = mnk_stage_bytes(g.NW, g.C, B);
   const dim3 grid((unsigned)((N + B - 1) / B));
-  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_observe), grid, dim3(B), lds, (hipStream_t)stream, g, planes, N,
-                                         flip_side, obs, legal_mask, fix_empty_mask, vec_ok));
+  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_observe), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, planes, N,
+                                         flip_side, obs, legal_mask, fix_empty_mask, vec_ok, B));
   return mnk_launch_status("observe");
 }
 
@@ -717,7 +751,7 @@ int mnk_unpack_boards(const uint64_t* planes, float* boards, int64_t N, int m, i
 
 int mnk_pack_boards(const float* boards, uint64_t* planes, int64_t N, int m, int n, void* stream) {
   MnkGeom g;
-  int rc = mnk_check_geom(m, n, 1, &g);
+  int rc = mnk_geom_any_k(m, n, &g);
   if (rc != MNK_OK) return rc;
   if (!boards || !planes || N < 0) return MNK_EINVAL;
   if (N == 0) return MNK_OK;
@@ -743,8 +777,8 @@ int mnk_step(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, c
     const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
     const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B) : 0;
     const dim3 grid((unsigned)((N + B - 1) / B));
-    MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_step_full), grid, dim3(B), lds, s, g, planes, meta, N, actions,
-                                           rewards, dones, legal_mask, obs, err, flags, vec_ok));
+    MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_step_full), grid, dim3(mnk_block_threads()), lds, s, g, planes, meta, N, actions,
+                                           rewards, dones, legal_mask, obs, err, flags, vec_ok, B));
     return mnk_launch_status("step");
   }
   // subset: full-size zero rewards / dones (:75, :79), scatter the active ones, then a full observe
@@ -765,7 +799,7 @@ int mnk_step(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, c
 int mnk_sample_legal(const uint64_t* planes, int64_t N, int m, int n, uint64_t seed, uint64_t step, int64_t env_id0,
                      int stream_id, int64_t* actions, void* stream) {
   MnkGeom g;
-  int rc = mnk_check_geom(m, n, 1, &g);
+  int rc = mnk_geom_any_k(m, n, &g);
   if (rc != MNK_OK) return rc;
   if (!planes || !actions || N < 0 || stream_id < 0 || stream_id > 255) return MNK_EINVAL;
   if (N == 0) return MNK_OK;
@@ -835,9 +869,9 @@ int mnk_selfplay_pre(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, 
   const int vec_ok = (aligned16(opp_obs) ? 1 : 0) | (aligned16(opp_mask) ? 2 : 0);
   const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B) : 0;
   const dim3 grid((unsigned)((N + B - 1) / B));
-  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_pre), grid, dim3(B), lds, (hipStream_t)stream, g, planes, meta,
+  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_pre), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, planes, meta,
                                          N, actions, pending, agent_side, forced_side, seed, step, env_id0, rewards,
-                                         terminated, sp_flags, opp_obs, opp_mask, err, vec_ok));
+                                         terminated, sp_flags, opp_obs, opp_mask, err, vec_ok, B));
   return mnk_launch_status("selfplay_pre");
 }
 
@@ -855,9 +889,9 @@ int mnk_selfplay_post(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n,
   const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
   const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B) : 0;
   const dim3 grid((unsigned)((N + B - 1) / B));
-  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_post), grid, dim3(B), lds, (hipStream_t)stream, g, planes,
+  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_post), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, planes,
                                          meta, N, opp_actions, sp_flags, agent_side, rewards, terminated, pending, obs,
-                                         legal_mask, err, vec_ok));
+                                         legal_mask, err, vec_ok, B));
   return mnk_launch_status("selfplay_post");
 }
 
@@ -875,9 +909,9 @@ int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m,
   const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
   const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B) : 0;
   const dim3 grid((unsigned)((N + B - 1) / B));
-  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_step_random), grid, dim3(B), lds, (hipStream_t)stream, g,
+  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_step_random), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g,
                                          planes, meta, N, actions, pending, agent_side, forced_side, seed, step,
-                                         env_id0, rewards, terminated, obs, legal_mask, err, vec_ok));
+                                         env_id0, rewards, terminated, obs, legal_mask, err, vec_ok, B));
   return mnk_launch_status("selfplay_step_random");
 }
 
@@ -886,15 +920,15 @@ int mnk_sample_logits(const float* logits, const uint8_t* mask, int64_t N, int C
   if (!logits || !mask || !actions || N < 0 || C < 1 || C > 65535) return MNK_EINVAL;
   if (N == 0) return MNK_OK;
   if (N > 0x7fffffffLL) return MNK_EINVAL;
-  hipLaunchKernelGGL(k_sample_logits, dim3((unsigned)N), dim3(64), 0, (hipStream_t)stream, logits, mask, N, C, seed,
-                     step, env_id0, deterministic, actions, logp);
+  hipLaunchKernelGGL(k_sample_logits, dim3((unsigned)((N + 1) / 2)), dim3(64), 0, (hipStream_t)stream, logits, mask, N,
+                     C, seed, step, env_id0, deterministic, actions, logp);
   return mnk_launch_status("sample_logits");
 }
 
 int mnk_unpack_records(const uint64_t* rec_planes, const uint32_t* rec_meta, int64_t N, int T, int m, int n,
                        float* obs, uint8_t* masks, int64_t* actions, float* rewards, uint8_t* dones, void* stream) {
   MnkGeom g;
-  int rc = mnk_check_geom(m, n, 1, &g);
+  int rc = mnk_geom_any_k(m, n, &g);
   if (rc != MNK_OK) return rc;
   if (!rec_meta || N < 0 || T < 0 || T > 65535 || ((obs || masks) && !rec_planes)) return MNK_EINVAL;
   if (N == 0 || T == 0) return MNK_OK;
@@ -906,8 +940,8 @@ int mnk_unpack_records(const uint64_t* rec_planes, const uint32_t* rec_meta, int
   const int vec_ok = (obs_vec ? 1 : 0) | (mask_vec ? 2 : 0);
   const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B) : 0;
   const dim3 grid((unsigned)((N + B - 1) / B), (unsigned)T);
-  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_unpack_records), grid, dim3(B), lds, (hipStream_t)stream, g, rec_planes,
-                                         rec_meta, N, obs, masks, actions, rewards, dones, vec_ok));
+  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_unpack_records), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, rec_planes,
+                                         rec_meta, N, obs, masks, actions, rewards, dones, vec_ok, B));
   return mnk_launch_status("unpack_records");
 }
 
