@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, host cores): the CPU share of one GPU")
     ap.add_argument("--no-api-path", action="store_true", help="skip the extra per-step-launch measurement")
+    ap.add_argument("--mode", choices=("rollout", "selfplay"), default="rollout",
+                    help="rollout = the BASELINE.json metric (default); selfplay = BASELINE config 3: the wrapper loop "
+                         "with a small conv policy as agent and an opponent pool (agent-steps/s, NN time dominates)")
     ap.add_argument("--backend", default="nccl", help="process-group backend; nccl = RCCL.  gloo is for rehearsing "
                     "the multi-rank path on a one-GPU box (all ranks then share device 0)")
     ap.add_argument("--gather", choices=("actions", "records", "none"), default="actions",
@@ -159,8 +162,129 @@ def replay_rate(env, roll, chunk, reps=8):
     return reps * chunk * env.num_envs / (time.perf_counter() - t0)
 
 
+def selfplay_mode(args):
+    """BASELINE.json config 3: full self-play rollout through TorchSelfPlayWrapper with a small conv
+    policy (the shape of the reference's cnn_b_s: 4 x [conv3x3(56) + BN + ReLU], 1x1-conv heads,
+    alg/architectures/configs.py:49-56) as agent and a pool of 4 frozen opponents rotated every 64 steps.
+    The networks are the caller's side of the boundary (PyTorch-ROCm / MIOpen, bf16 autocast, eval mode);
+    what this build contributes are the two env kernels and the fused mask+softmax+draw per step."""
+    import torch.nn as nn
+
+    import mnk_hip
+    from env.torch_vector_mnk_env import TorchVectorMnkEnv
+    from selfplay.opponent_pool import OpponentPool
+    from selfplay.policy import FusedNNPolicy
+    from selfplay.torch_self_play_wrapper import TorchSelfPlayWrapper
+
+    mnk_hip.load()
+    dev = torch.device("cuda", 0)
+    m, n, k = (int(v) for v in args.board.split("x"))
+    c, nenv = m * n, args.envs
+
+    class ConvPolicy(nn.Module):
+        def __init__(self, width=56, hidden=128):
+            super().__init__()
+            layers, cin = [], 2
+            for _ in range(4):
+                layers += [nn.Conv2d(cin, width, 3, padding=1), nn.BatchNorm2d(width), nn.ReLU()]
+                cin = width
+            self.body = nn.Sequential(*layers)
+            self.folded = False
+
+            def head(ch, out, squash):
+                mods = [nn.Conv2d(width, ch, 1), nn.Flatten(), nn.LayerNorm(ch * c), nn.ReLU(),
+                        nn.Linear(ch * c, hidden), nn.LayerNorm(hidden), nn.ReLU(), nn.Linear(hidden, out)]
+                return nn.Sequential(*(mods + ([nn.Tanh()] if squash else [])))
+
+            self.actor, self.critic = head(2, c, False), head(1, 1, True)
+
+        def fold_batchnorm(self):
+            """eval-mode inference: BatchNorm folded into the preceding conv (MIOpen's NHWC bf16 BatchNorm
+            inference kernel alone takes 135 ms at this batch -- 17x the four convolutions)"""
+            mods = list(self.body)
+            out = []
+            for a, b in zip(mods, mods[1:] + [None]):
+                if isinstance(a, nn.Conv2d) and isinstance(b, nn.BatchNorm2d):
+                    out.append(nn.utils.fusion.fuse_conv_bn_eval(a, b))
+                elif not isinstance(a, nn.BatchNorm2d):
+                    out.append(a)
+            self.body = nn.Sequential(*out)
+            self.folded = True
+            return self
+
+        def forward(self, obs, action_mask=None):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                f = self.body(obs.contiguous(memory_format=torch.channels_last))
+                logits, value = self.actor(f).float(), self.critic(f).float()
+            if action_mask is not None:
+                logits = torch.where(action_mask, logits, torch.full_like(logits, -torch.inf))
+            return torch.distributions.Categorical(logits=logits, validate_args=False), value
+
+    torch.manual_seed(args.seed)
+    nets = [ConvPolicy().to(dev).eval().fold_batchnorm().to(memory_format=torch.channels_last) for _ in range(5)]
+    agent = FusedNNPolicy(nets[0], seed=args.seed)
+    pool = OpponentPool(max_size=4)
+    for net in nets[1:]:
+        pool.add_opponent(FusedNNPolicy(net, seed=args.seed + 1))
+    env = TorchVectorMnkEnv(m, n, k, nenv, device=str(dev))
+    wrap = TorchSelfPlayWrapper(env, seed=args.seed)
+    opponents = list(pool.pool)
+    wrap.set_opponent(opponents[0])
+    obs, _ = wrap.reset()
+    state = {"obs": obs, "plies": torch.zeros((), dtype=torch.long, device=dev)}
+
+    def step(t):
+        if t % 64 == 0:
+            wrap.set_opponent(opponents[(t // 64) % len(opponents)])
+        before = env._meta >> 1
+        actions = agent.act(state["obs"])
+        state["obs"], rew, term, trunc, _ = wrap.step(actions)
+        # plies played this step = growth of the move counters (resets restart them at 0 or 1)
+        state["plies"] += torch.clamp((env._meta >> 1) - before, min=0).sum()
+
+    steps, warm = min(args.steps, 256), min(args.warmup, 64)
+    for t in range(warm):
+        step(t)
+    state["plies"].zero_()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for t in range(steps):
+        step(warm + t)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    # time of the env-side work alone: the same kernels with a constant-action opponent and agent
+    class Const:
+        def act(self, o):
+            return torch.zeros(nenv, dtype=torch.long, device=dev)
+    wrap.set_opponent(Const())
+    acts = torch.zeros(nenv, dtype=torch.long, device=dev)
+    for _ in range(5):
+        wrap.step(acts)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for _ in range(50):
+        wrap.step(acts)
+    torch.cuda.synchronize(dev)
+    env_ms = (time.perf_counter() - t1) * 1e3 / 50
+    out = {
+        "metric": f"agent-steps/sec {m}x{n}x{k}, {nenv} envs, self-play rollout with conv policy + opponent pool",
+        "value": nenv * steps / dt, "unit": "agent-steps/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+        "ms_per_step": dt * 1e3 / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64 env state; bf16 autocast policy (caller side)", "data": "synthetic",
+        "config": {"workload": f"{m}x{n}x{k}, {nenv} envs, TorchSelfPlayWrapper loop, agent = opponent pool of 4 = "
+                               "random-init 4x conv3x3(56) policies, fused mask+softmax+draw", "envs_per_gpu": nenv},
+        "env_steps_per_s": float(state["plies"].item()) / dt,
+        "env_side_ms_per_step": env_ms,
+        "nn_and_sampling_ms_per_step": dt * 1e3 / steps - env_ms,
+        "roofline": None, "cpu_baseline": None,
+    }
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
+    if args.mode == "selfplay":
+        return selfplay_mode(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -341,3 +341,43 @@ def test_ppo_rollout_call_pattern(hip):
         obs = next_obs
     assert finished > nenv  # games end and restart
     assert set(rewards.unique().tolist()) <= {-1.0, 0.0, 1.0}
+
+
+def test_rollout_buffer_dropin(hip):
+    """alg/rollout_buffer.py surface: add / full-buffer error / GAE (bit-exact vs the f32 restatement of
+    rollout_buffer.py:60-80) / minibatch generator, including a partially filled buffer."""
+    from alg.rollout_buffer import RolloutBuffer
+
+    t, n, c = 16, 300, 9
+    buf = RolloutBuffer(t, n, (2, 3, 3), c, device=DEV)
+    rng = np.random.default_rng(1)
+    rows = []
+    for step in range(11):  # partially filled: ptr = 11 < n_steps
+        obs = torch.from_numpy(rng.integers(0, 2, (n, 2, 3, 3)).astype(np.float32)).to(DEV)
+        act = torch.from_numpy(rng.integers(0, c, n)).to(DEV)
+        rew = torch.from_numpy(rng.choice([-1.0, 0.0, 1.0], n).astype(np.float32)).to(DEV)
+        val = torch.from_numpy(rng.standard_normal((n, 1)).astype(np.float32)).to(DEV)
+        lp = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(DEV)
+        done = torch.from_numpy(rng.random(n) < 0.1).to(DEV)
+        mask = torch.from_numpy(rng.random((n, c)) < 0.7).to(DEV)
+        buf.add(obs, act, rew, val, lp, done, mask)
+        rows.append((rew.cpu().numpy(), val.cpu().numpy().reshape(-1), done.cpu().numpy()))
+    assert buf.ptr == 11
+    last = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(DEV)
+    buf.compute_advantages_and_returns(last, 0.99, 0.95)
+    rewards, values, dones = (np.stack(x) for x in zip(*rows))
+    want_adv, want_ret = oracle_gae(rewards, values, dones, last.cpu().numpy(), 0.99, 0.95)
+    assert np.array_equal(buf.advantages[:11].cpu().numpy(), want_adv)
+    assert np.array_equal(buf.returns[:11].cpu().numpy(), want_ret)
+    assert float(buf.advantages[11:].abs().sum()) == 0.0
+    seen = 0
+    for obs_b, act_b, lp_b, ret_b, adv_b, mask_b, val_b in buf.get_data_loader(1000):
+        assert obs_b.shape[1:] == (2, 3, 3) and mask_b.shape[1] == c and act_b.dtype == torch.long
+        seen += obs_b.shape[0]
+    assert seen == 11 * n
+    for _ in range(5):
+        buf.add(obs, act, rew, val, lp, done, mask)
+    with pytest.raises(IndexError, match="Buffer was full."):
+        buf.add(obs, act, rew, val, lp, done, mask)
+    buf.reset()
+    assert buf.ptr == 0 and float(buf.rewards.abs().sum()) == 0.0
