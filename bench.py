@@ -151,7 +151,7 @@ def replay_rate(env, roll, chunk, reps=8):
     rec = roll.alloc(chunk, log_actions=True)
     roll.run(chunk, out=rec)
     logs = GatheredLogs(planes0=rec.planes[0].unsqueeze(0).clone(), meta0=rec.meta0.unsqueeze(0).clone(),
-                        act=rec.act.unsqueeze(0))
+                        act=rec.act.unsqueeze(0), steps=chunk)
     out = replay_shard(logs, 0, env.m, env.n, env.k)
     assert torch.equal(out.planes, rec.planes) and torch.equal(out.meta, rec.meta), "replay != records"
     torch.cuda.synchronize()
@@ -327,8 +327,9 @@ def main():
         else:
             gathered = [GatheredLogs(planes0=torch.empty((world, 2, env.words, nenv), dtype=torch.int64, device=dev),
                                      meta0=torch.empty((world, nenv), dtype=torch.int32, device=dev),
-                                     act=torch.empty((world, chunk, nenv), dtype=action_log_dtype(env.max_moves),
-                                                     device=dev)) for _ in bufs]
+                                     act=torch.empty((world, (chunk + 3) // 4, nenv),
+                                                     dtype=action_log_dtype(env.max_moves), device=dev),
+                                     steps=chunk) for _ in bufs]
     main_stream = torch.cuda.current_stream(dev)
     gather_done = [None, None]
     kernel_events = []  # (start, end) HIP events around every rollout launch of the timed region
@@ -347,7 +348,7 @@ def main():
             out = bufs[slot]
             if t != chunk:
                 out = RolloutRecords(planes=out.planes[:t], meta=out.meta[:t],
-                                     act=None if out.act is None else out.act[:t], meta0=out.meta0)
+                                     act=None if out.act is None else out.act[:(t + 3) // 4], meta0=out.meta0)
             if timing[0]:
                 ks, ke = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ks.record(main_stream)

@@ -171,9 +171,12 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
                        void* act_log, int act_bytes, void* stream);
 
 /* The multi-GPU exchange format.  A shard's rollout is a pure function of its chunk-start state and
- * its actions, so the action log -- act_log u8[T][N] (act_bytes 1, boards with <= 256 cells) or
- * u16[T][N] (act_bytes 2), optionally written by mnk_rollout_random -- is what ranks all-gather
+ * its actions, so the action log, optionally written by mnk_rollout_random, is what ranks all-gather
  * (1-2 B per env-step instead of the 36 B packed record or the reference's 750 B RolloutBuffer row).
+ * Layout: four plies per word, act_log u32[ceil(T/4)][N] (act_bytes 1: one byte per action, boards with
+ * <= 256 cells) or u64[ceil(T/4)][N] (act_bytes 2: 16 bits per action); the action of ply 4q+j is field j
+ * (little-endian) of word [q][i]; fields past T are 0.  With a log, step0 must be a multiple of 4 (every
+ * chunk but the last a multiple of 4 plies).
  * mnk_replay_actions re-plays a log from `planes`/`meta` (updated in place, like the rollout) and
  * rebuilds rec_planes / rec_meta bit-identical to what the sender recorded (both may be NULL to only
  * advance the state).  An action >= m*n in the log is reported through err. */

@@ -1,0 +1,111 @@
+// mnk_host.h -- host-side helpers shared by the translation units of libmnk_hip.so:
+// geometry construction, kernel-variant dispatch, launch-status bookkeeping.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/mnk_hip.h"
+#include "mnk_device.h"
+#include "mnk_emit.h"
+
+// ------------------------------------------------------------------ host helpers
+inline thread_local char g_launch_err[256] = "";
+
+inline int mnk_make_geom(int m, int n, int k, MnkGeom* g) {
+  if (m < 1 || n < 1 || k < 1 || k > m || k > n || n > 61) return MNK_EGEOM;
+  const int bits = m * (n + 1);
+  const int W = (bits + 63) / 64;
+  if (W > MNK_MAX_W) return MNK_EGEOM;
+  memset(g, 0, sizeof(*g));
+  g->m = m; g->n = n; g->k = k;
+  g->C = m * n; g->W = W; g->NW = (bits + 31) / 32; g->stride = n + 1;
+  auto magic = [](uint32_t d) { return (uint32_t)((1ull << 32) / d + 1ull); };
+  g->magic_n = n == 1 ? 0u : magic((uint32_t)n);  // n == 1: x / 1 handled below
+  g->magic_stride = magic((uint32_t)(n + 1));
+  g->magic_C = g->C == 1 ? 0u : magic((uint32_t)g->C);
+  g->magic_2C = magic((uint32_t)(2 * g->C));
+  for (int r = 0; r < m; ++r)
+    for (int c = 0; c < n; ++c) {
+      const int b = r * (n + 1) + c;
+      g->valid[b >> 5] |= 1u << (b & 31);
+    }
+  return MNK_OK;
+}
+
+// division by 1 cannot use the 32-bit magic (2^32 + 1 overflows); boards with n == 1 or a
+// single cell are degenerate and rejected instead of carrying a special case in every kernel
+inline int mnk_check_geom(int m, int n, int k, MnkGeom* g) {
+  int rc = mnk_make_geom(m, n, k, g);
+  if (rc != MNK_OK) return rc;
+  if (n < 2) return MNK_EGEOM;
+  return MNK_OK;
+}
+
+// kernels that never look at k (observe, samplers, unpack): hand the dispatcher the k of the
+// specialised variant of that board width so they take the compile-time-geometry path too
+inline int mnk_geom_any_k(int m, int n, MnkGeom* g) {
+  int rc = mnk_check_geom(m, n, 1, g);
+  if (rc != MNK_OK) return rc;
+  if (n == 3) g->k = 3;
+  if (n == 9 || n == 13 || n == 15 || n == 19) g->k = 5;
+  return MNK_OK;
+}
+
+inline int mnk_launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return MNK_OK;
+  snprintf(g_launch_err, sizeof(g_launch_err), "%s: %s", what, hipGetErrorString(e));
+  return MNK_ELAUNCH;
+}
+
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// workgroup size for kernels with a write-out stage (envs per workgroup)
+inline int mnk_block_envs(int64_t N) {
+  (void)N;
+  static int cached = 0;
+  if (!cached) {
+    const char* v = getenv("MNK_EMIT_ENVS");
+    int t = v ? atoi(v) : 64;
+    cached = (t == 16 || t == 32 || t == 64) ? t : 64;
+  }
+  return cached;
+}
+
+// threads per workgroup of those kernels: the first 64 lanes play their envs, then all waves of
+// the workgroup sweep its output slab (more waves per SIMD to hide the LDS / store latency)
+inline int mnk_block_threads() {
+  static int cached = 0;
+  if (!cached) {
+    const char* v = getenv("MNK_EMIT_THREADS");
+    int t = v ? atoi(v) : 256;
+    cached = (t == 64 || t == 128 || t == 256) ? t : 256;  // kernels are __launch_bounds__(256)
+  }
+  return cached;
+}
+
+// Kernel variants: NW = u32 register words per plane; CN / CK = compile-time board width and
+// run length (0 = run time).  The boards people actually train on get fully specialised code
+// (immediate shift amounts, unrolled run doubling); everything else takes the generic form.
+#define MNK_CASE(NWv, CNv, CKv, ...)                      \
+  {                                                       \
+    constexpr int NW = NWv, CN = CNv, CK = CKv;           \
+    __VA_ARGS__;                                          \
+  }
+#define MNK_DISPATCH(g, ...)                                                          \
+  do {                                                                                \
+    if ((g).n == 9 && (g).k == 5 && (g).NW == 3) MNK_CASE(3, 9, 5, __VA_ARGS__)       \
+    else if ((g).n == 3 && (g).k == 3 && (g).NW == 1) MNK_CASE(1, 3, 3, __VA_ARGS__)  \
+    else if ((g).n == 13 && (g).k == 5 && (g).NW == 6) MNK_CASE(6, 13, 5, __VA_ARGS__) \
+    else if ((g).n == 15 && (g).k == 5 && (g).NW == 8) MNK_CASE(8, 15, 5, __VA_ARGS__) \
+    else if ((g).n == 19 && (g).k == 5 && (g).NW == 12) MNK_CASE(12, 19, 5, __VA_ARGS__) \
+    else if ((g).NW <= 2) MNK_CASE(2, 0, 0, __VA_ARGS__)                              \
+    else if ((g).NW <= 4) MNK_CASE(4, 0, 0, __VA_ARGS__)                              \
+    else if ((g).NW <= 8) MNK_CASE(8, 0, 0, __VA_ARGS__)                              \
+    else MNK_CASE(16, 0, 0, __VA_ARGS__)                                              \
+  } while (0)
+#define MNK_K(name) HIP_KERNEL_NAME(name<NW, CN, CK>)
+

@@ -7,113 +7,7 @@
 // (coalesced 8-byte accesses over the env axis of the SoA state), one workgroup per
 // B consecutive envs, and the same env -> workgroup map in every kernel so an env's
 // state stays in the L2 of the XCD that touched it last.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-
-#include "../../include/mnk_hip.h"
-#include "mnk_device.h"
-#include "mnk_emit.h"
-
-// ------------------------------------------------------------------ host helpers
-static thread_local char g_launch_err[256] = "";
-
-static int mnk_make_geom(int m, int n, int k, MnkGeom* g) {
-  if (m < 1 || n < 1 || k < 1 || k > m || k > n || n > 61) return MNK_EGEOM;
-  const int bits = m * (n + 1);
-  const int W = (bits + 63) / 64;
-  if (W > MNK_MAX_W) return MNK_EGEOM;
-  memset(g, 0, sizeof(*g));
-  g->m = m; g->n = n; g->k = k;
-  g->C = m * n; g->W = W; g->NW = (bits + 31) / 32; g->stride = n + 1;
-  auto magic = [](uint32_t d) { return (uint32_t)((1ull << 32) / d + 1ull); };
-  g->magic_n = n == 1 ? 0u : magic((uint32_t)n);  // n == 1: x / 1 handled below
-  g->magic_stride = magic((uint32_t)(n + 1));
-  g->magic_C = g->C == 1 ? 0u : magic((uint32_t)g->C);
-  g->magic_2C = magic((uint32_t)(2 * g->C));
-  for (int r = 0; r < m; ++r)
-    for (int c = 0; c < n; ++c) {
-      const int b = r * (n + 1) + c;
-      g->valid[b >> 5] |= 1u << (b & 31);
-    }
-  return MNK_OK;
-}
-
-// division by 1 cannot use the 32-bit magic (2^32 + 1 overflows); boards with n == 1 or a
-// single cell are degenerate and rejected instead of carrying a special case in every kernel
-static int mnk_check_geom(int m, int n, int k, MnkGeom* g) {
-  int rc = mnk_make_geom(m, n, k, g);
-  if (rc != MNK_OK) return rc;
-  if (n < 2) return MNK_EGEOM;
-  return MNK_OK;
-}
-
-// kernels that never look at k (observe, samplers, unpack): hand the dispatcher the k of the
-// specialised variant of that board width so they take the compile-time-geometry path too
-static int mnk_geom_any_k(int m, int n, MnkGeom* g) {
-  int rc = mnk_check_geom(m, n, 1, g);
-  if (rc != MNK_OK) return rc;
-  if (n == 3) g->k = 3;
-  if (n == 9 || n == 13 || n == 15 || n == 19) g->k = 5;
-  return MNK_OK;
-}
-
-static int mnk_launch_status(const char* what) {
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) return MNK_OK;
-  snprintf(g_launch_err, sizeof(g_launch_err), "%s: %s", what, hipGetErrorString(e));
-  return MNK_ELAUNCH;
-}
-
-static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
-
-// workgroup size for kernels with a write-out stage (envs per workgroup)
-static int mnk_block_envs(int64_t N) {
-  (void)N;
-  static int cached = 0;
-  if (!cached) {
-    const char* v = getenv("MNK_EMIT_ENVS");
-    int t = v ? atoi(v) : 64;
-    cached = (t == 16 || t == 32 || t == 64) ? t : 64;
-  }
-  return cached;
-}
-
-// threads per workgroup of those kernels: the first 64 lanes play their envs, then all waves of
-// the workgroup sweep its output slab (more waves per SIMD to hide the LDS / store latency)
-static int mnk_block_threads() {
-  static int cached = 0;
-  if (!cached) {
-    const char* v = getenv("MNK_EMIT_THREADS");
-    int t = v ? atoi(v) : 256;
-    cached = (t == 64 || t == 128 || t == 256) ? t : 256;  // kernels are __launch_bounds__(256)
-  }
-  return cached;
-}
-
-// Kernel variants: NW = u32 register words per plane; CN / CK = compile-time board width and
-// run length (0 = run time).  The boards people actually train on get fully specialised code
-// (immediate shift amounts, unrolled run doubling); everything else takes the generic form.
-#define MNK_CASE(NWv, CNv, CKv, ...)                      \
-  {                                                       \
-    constexpr int NW = NWv, CN = CNv, CK = CKv;           \
-    __VA_ARGS__;                                          \
-  }
-#define MNK_DISPATCH(g, ...)                                                          \
-  do {                                                                                \
-    if ((g).n == 9 && (g).k == 5 && (g).NW == 3) MNK_CASE(3, 9, 5, __VA_ARGS__)       \
-    else if ((g).n == 3 && (g).k == 3 && (g).NW == 1) MNK_CASE(1, 3, 3, __VA_ARGS__)  \
-    else if ((g).n == 13 && (g).k == 5 && (g).NW == 6) MNK_CASE(6, 13, 5, __VA_ARGS__) \
-    else if ((g).n == 15 && (g).k == 5 && (g).NW == 8) MNK_CASE(8, 15, 5, __VA_ARGS__) \
-    else if ((g).n == 19 && (g).k == 5 && (g).NW == 12) MNK_CASE(12, 19, 5, __VA_ARGS__) \
-    else if ((g).NW <= 2) MNK_CASE(2, 0, 0, __VA_ARGS__)                              \
-    else if ((g).NW <= 4) MNK_CASE(4, 0, 0, __VA_ARGS__)                              \
-    else if ((g).NW <= 8) MNK_CASE(8, 0, 0, __VA_ARGS__)                              \
-    else MNK_CASE(16, 0, 0, __VA_ARGS__)                                              \
-  } while (0)
-#define MNK_K(name) HIP_KERNEL_NAME(name<NW, CN, CK>)
+#include "mnk_host.h"
 
 // ------------------------------------------------------------------ reset
 __global__ void k_reset_idx(uint64_t* planes, uint32_t* meta, int64_t N, int W, const int64_t* idx, int64_t R,
@@ -247,132 +141,6 @@ k_sample_legal(MnkGeom g, const uint64_t* planes, int64_t N, uint64_t seed, uint
   e.meta = 0u;
   const uint32_t x = mnk_rand_u32(seed, (uint64_t)(env_id0 + i), step, stream_id);
   actions[i] = env_pick_legal<NW, CN>(g, e, x);
-}
-
-// ------------------------------------------------------------------ fused random rollout
-// T plies per env in one launch; state lives in registers, HBM sees one load and one
-// store of the state per launch plus the 36-byte (9x9) record of every ply.
-// The loop is laid out for a wave that is alone on its SIMD (65 536 envs = 1024 waves =
-// one per SIMD): no divergent branch, per-lane bookkeeping instead of per-ply ballots
-// (scalar round trips), four plies per Philox block with the word picked at compile time.
-template <int NW, int CN, int CK, bool RECORD>
-struct RolloutLane {
-  static constexpr bool EXACT = CN != 0;
-  const MnkGeom& g;
-  MnkEnv<NW> e;
-  int64_t N, i;
-  uint64_t* rec_planes;
-  uint32_t* rec_meta;
-  uint8_t* act8 = nullptr;    // optional action log, one byte per ply (boards with <= 256 cells)
-  uint16_t* act16 = nullptr;  // ... or two bytes per ply
-  uint32_t acc_done_draw = 0;    // finished games | draws << 16   (T <= 65535 per launch)
-  uint32_t acc_black_white = 0;  // black wins | white wins << 16
-  uint32_t len_sum = 0;
-
-  __device__ __forceinline__ RolloutLane(const MnkGeom& g_) : g(g_) {}
-
-  __device__ __forceinline__ void ply(int t, uint32_t x) {
-    const int a = env_pick_legal<NW, CN>(g, e, x);
-    if (act8) act8[(int64_t)t * N + i] = (uint8_t)a;
-    if (act16) act16[(int64_t)t * N + i] = (uint16_t)a;
-    ply_action(t, a);
-  }
-
-  // one ply with a known-good action (from the sampler, or from an action log the sampler wrote)
-  __device__ __forceinline__ void ply_action(int t, int a) {
-    if (RECORD) {
-      uint64_t* rp = rec_planes + (int64_t)t * 2 * g.W * N;
-      plane_store<NW, EXACT>(e.p[0], rp, N, g.W, i);
-      plane_store<NW, EXACT>(e.p[1], rp + (int64_t)g.W * N, N, g.W, i);
-    }
-    const uint32_t side = e.meta & 1u;
-    const MnkPly p = env_play<NW, CN, CK, true>(g, e, a, false);
-    const uint32_t win = p.win ? 1u : 0u, done = p.done ? 1u : 0u;
-    if (RECORD)
-      rec_meta[(int64_t)t * N + i] = (uint32_t)a | (win << MNK_REC_REWARD_SHIFT) | (done << MNK_REC_DONE_BIT) |
-                                     (side << MNK_REC_SIDE_BIT);
-    acc_done_draw += done + ((done & ~win) << 16);
-    acc_black_white += (win & ~side) + ((win & side) << 16);
-    len_sum += p.done ? (e.meta >> 1) : 0u;
-    if (p.done) env_clear<NW>(e);  // env.reset(nonzero(done)) :34-44
-  }
-};
-
-template <int NW, int CN, int CK, bool RECORD>
-__global__ void __launch_bounds__(64)
-k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed, uint64_t step0,
-                 int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, unsigned long long* stats,
-                 void* act_log, int act_bytes) {
-  // one full wave of 64 envs per workgroup: half-filled waves were measured and are slower
-  // (gfx950 does not skip the idle half of a wave64), see DESIGN.md
-  __shared__ unsigned int lds_stats[MNK_STATS_COUNTERS];
-  if (threadIdx.x < MNK_STATS_COUNTERS) lds_stats[threadIdx.x] = 0u;
-  __syncthreads();
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N) {
-    RolloutLane<NW, CN, CK, RECORD> L(g);
-    L.N = N; L.i = i; L.rec_planes = rec_planes; L.rec_meta = rec_meta;
-    if (act_bytes == 1) L.act8 = (uint8_t*)act_log;
-    if (act_bytes == 2) L.act16 = (uint16_t*)act_log;
-    env_load<NW, L.EXACT>(L.e, planes, meta, N, g.W, i);
-    const uint64_t env = (uint64_t)(env_id0 + i);
-    int t = 0;
-    uint64_t step = step0;
-    if (step & 3) {  // head: finish the Philox block the previous launch stopped in
-      const Philox4 blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
-      for (; t < T && (step & 3); ++t, ++step) L.ply(t, philox_word(blk, (uint32_t)(step & 3)));
-    }
-    for (; t + 4 <= T; t += 4, step += 4) {
-      const Philox4 blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
-      L.ply(t, blk.v[0]);
-      L.ply(t + 1, blk.v[1]);
-      L.ply(t + 2, blk.v[2]);
-      L.ply(t + 3, blk.v[3]);
-    }
-    if (t < T) {
-      const Philox4 blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
-      for (uint32_t j = 0; t < T; ++t, ++j) L.ply(t, philox_word(blk, j));
-    }
-    env_store<NW, L.EXACT>(L.e, planes, meta, N, g.W, i);
-    if (stats) {
-      if (L.acc_done_draw & 0xFFFFu) atomicAdd(&lds_stats[0], L.acc_done_draw & 0xFFFFu);
-      if (L.acc_black_white & 0xFFFFu) atomicAdd(&lds_stats[1], L.acc_black_white & 0xFFFFu);
-      if (L.acc_black_white >> 16) atomicAdd(&lds_stats[2], L.acc_black_white >> 16);
-      if (L.acc_done_draw >> 16) atomicAdd(&lds_stats[3], L.acc_done_draw >> 16);
-      if (L.len_sum) atomicAdd(&lds_stats[4], L.len_sum);
-    }
-  }
-  __syncthreads();
-  // one global atomic per counter per wave, spread over MNK_STATS_REPLICAS cache lines: thousands
-  // of adds on five addresses would serialise at ~11 ns each (measured: 56 us per launch)
-  if (stats && threadIdx.x < MNK_STATS_COUNTERS && lds_stats[threadIdx.x])
-    atomicAdd(&stats[(size_t)(blockIdx.x % MNK_STATS_REPLICAS) * MNK_STATS_STRIDE + threadIdx.x],
-              (unsigned long long)lds_stats[threadIdx.x]);
-}
-
-// ------------------------------------------------------------------ replay of an action log
-// The receiving side of the multi-GPU exchange: a shard's rollout is fully determined by its
-// chunk-start state and its action log (1-2 bytes per ply), so that is what crosses xGMI; this
-// kernel re-plays the log and rebuilds the full packed records, bit-identical to the sender's.
-template <int NW, int CN, int CK, bool RECORD>
-__global__ void __launch_bounds__(64)
-k_replay_actions(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, const void* act_log, int act_bytes,
-                 uint64_t* rec_planes, uint32_t* rec_meta, int32_t* err) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  RolloutLane<NW, CN, CK, RECORD> L(g);
-  L.N = N; L.i = i; L.rec_planes = rec_planes; L.rec_meta = rec_meta;
-  env_load<NW, L.EXACT>(L.e, planes, meta, N, g.W, i);
-  const uint8_t* a8 = (const uint8_t*)act_log;
-  const uint16_t* a16 = (const uint16_t*)act_log;
-  bool bad = false;
-  for (int t = 0; t < T; ++t) {
-    int a = act_bytes == 1 ? (int)a8[(int64_t)t * N + i] : (int)a16[(int64_t)t * N + i];
-    if (a >= g.C) { bad = true; a = 0; }  // a log we did not write: flag it, keep the wave in step
-    L.ply_action(t, a);
-  }
-  if (bad) mnk_report(err, MNK_ERR_ACTION_RANGE, i);
-  env_store<NW, L.EXACT>(L.e, planes, meta, N, g.W, i);
 }
 
 // ------------------------------------------------------------------ fused self-play step
@@ -808,50 +576,6 @@ int mnk_sample_legal(const uint64_t* planes, int64_t N, int m, int n, uint64_t s
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_sample_legal), grid, dim3(B), 0, (hipStream_t)stream, g, planes, N, seed,
                                          step, env_id0, (uint32_t)stream_id, actions));
   return mnk_launch_status("sample_legal");
-}
-
-int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, int T, uint64_t seed,
-                       uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
-                       void* act_log, int act_bytes, void* stream) {
-  MnkGeom g;
-  int rc = mnk_check_geom(m, n, k, &g);
-  if (rc != MNK_OK) return rc;
-  if (!planes || !meta || N < 0 || T < 0 || T > 65535 || (!rec_planes != !rec_meta)) return MNK_EINVAL;
-  if (act_log && !(act_bytes == 2 || (act_bytes == 1 && g.C <= 256))) return MNK_EINVAL;
-  if (!act_log) act_bytes = 0;
-  if (N == 0 || T == 0) return MNK_OK;
-  const int B = 64;
-  const dim3 grid((unsigned)((N + B - 1) / B));
-  if (rec_planes && rec_meta)
-    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NW, CN, CK, true>), grid, dim3(B), 0,
-                                       (hipStream_t)stream, g, planes, meta, N, T, seed, step0, env_id0, rec_planes,
-                                       rec_meta, (unsigned long long*)stats, act_log, act_bytes));
-  else
-    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NW, CN, CK, false>), grid, dim3(B), 0,
-                                       (hipStream_t)stream, g, planes, meta, N, T, seed, step0, env_id0, nullptr,
-                                       nullptr, (unsigned long long*)stats, act_log, act_bytes));
-  return mnk_launch_status("rollout_random");
-}
-
-int mnk_replay_actions(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, int T, const void* act_log,
-                       int act_bytes, uint64_t* rec_planes, uint32_t* rec_meta, int32_t* err, void* stream) {
-  MnkGeom g;
-  int rc = mnk_check_geom(m, n, k, &g);
-  if (rc != MNK_OK) return rc;
-  if (!planes || !meta || !act_log || N < 0 || T < 0 || (!rec_planes != !rec_meta)) return MNK_EINVAL;
-  if (!(act_bytes == 2 || (act_bytes == 1 && g.C <= 256))) return MNK_EINVAL;
-  if (N == 0 || T == 0) return MNK_OK;
-  const int B = 64;
-  const dim3 grid((unsigned)((N + B - 1) / B));
-  if (rec_planes && rec_meta)
-    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_replay_actions<NW, CN, CK, true>), grid, dim3(B), 0,
-                                       (hipStream_t)stream, g, planes, meta, N, T, act_log, act_bytes, rec_planes,
-                                       rec_meta, err));
-  else
-    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_replay_actions<NW, CN, CK, false>), grid, dim3(B), 0,
-                                       (hipStream_t)stream, g, planes, meta, N, T, act_log, act_bytes, nullptr,
-                                       nullptr, err));
-  return mnk_launch_status("replay_actions");
 }
 
 int mnk_selfplay_pre(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const int64_t* actions,

@@ -1,0 +1,206 @@
+// mnk_rollout.hip -- the fused random-policy rollout and the replay of its action log
+// (gfx950 / MI355X only).  Separate translation unit: these kernels come in many variants
+// (board specialisation x record / action-log forms) and compile in parallel with the rest.
+#include "mnk_host.h"
+
+// ------------------------------------------------------------------ fused random rollout
+// T plies per env in one launch; state lives in registers, HBM sees one load and one
+// store of the state per launch plus the 36-byte (9x9) record of every ply.
+// The loop is laid out for a wave that is alone on its SIMD (65 536 envs = 1024 waves =
+// one per SIMD): no divergent branch, per-lane bookkeeping instead of per-ply ballots
+// (scalar round trips), four plies per Philox block with the word picked at compile time.
+// ACT = bytes per action of the optional action log (0 = none, 1 = u8, 2 = u16).  The log is stored
+// four plies per word -- u32[ceil(T/4)][N] (ACT 1) or u64[ceil(T/4)][N] (ACT 2), action of ply 4q+j in
+// field j of word [q][i] -- so a wave writes 256 / 512 contiguous bytes per store.  (One byte per lane per
+// ply was measured first: 64-byte partial-line writes from waves on different XCDs cost +20 % kernel time.)
+template <int NW, int CN, int CK, bool RECORD, int ACT = 0>
+struct RolloutLane {
+  static constexpr bool EXACT = CN != 0;
+  const MnkGeom& g;
+  MnkEnv<NW> e;
+  int64_t N;
+  // this lane's cursors into the record arrays; they advance by one ply's stride after every ply
+  uint64_t* rp = nullptr;  // rec_planes[t][0][0][i]
+  uint32_t* rm = nullptr;  // rec_meta[t][i]
+  uint8_t* ra = nullptr;   // act_log[t / 4][i]
+  uint64_t quad = 0;       // the actions of the current group of four plies
+  uint32_t acc_done_draw = 0;    // finished games | draws << 16   (T <= 65535 per launch)
+  uint32_t acc_black_white = 0;  // black wins | white wins << 16
+  uint32_t len_sum = 0;
+
+  __device__ __forceinline__ RolloutLane(const MnkGeom& g_, int64_t N_, int64_t i, uint64_t* rec_planes,
+                                         uint32_t* rec_meta, void* act_log)
+      : g(g_), N(N_) {
+    if (RECORD) { rp = rec_planes + i; rm = rec_meta + i; }
+    if (ACT) ra = (uint8_t*)act_log + i * 4 * ACT;
+  }
+
+  __device__ __forceinline__ void log_flush() {
+    if (ACT == 1) *(uint32_t*)ra = (uint32_t)quad;
+    if (ACT == 2) *(uint64_t*)ra = quad;
+    ra += N * 4 * ACT;
+    quad = 0;
+  }
+
+  // field = position of this ply inside its group of four (= step & 3; a compile-time constant in
+  // the unrolled main loop, so the log costs one shift-or per ply and one wide store per four)
+  __device__ __forceinline__ void ply(uint32_t x, int field) {
+    const int a = env_pick_legal<NW, CN>(g, e, x);
+    if (ACT) {
+      quad |= (uint64_t)(uint32_t)a << (8 * ACT * field);
+      if (field == 3) log_flush();
+    }
+    ply_action(a);
+  }
+
+  // one ply with a known-good action (from the sampler, or from an action log the sampler wrote)
+  __device__ __forceinline__ void ply_action(int a) {
+    if (RECORD) {
+      plane_store<NW, EXACT>(e.p[0], rp, N, g.W, 0);
+      plane_store<NW, EXACT>(e.p[1], rp + (int64_t)g.W * N, N, g.W, 0);
+      rp += (int64_t)2 * g.W * N;
+    }
+    const uint32_t side = e.meta & 1u;
+    const MnkPly p = env_play<NW, CN, CK, true>(g, e, a, false);
+    const uint32_t win = p.win ? 1u : 0u, done = p.done ? 1u : 0u;
+    if (RECORD) {
+      *rm = (uint32_t)a | (win << MNK_REC_REWARD_SHIFT) | (done << MNK_REC_DONE_BIT) | (side << MNK_REC_SIDE_BIT);
+      rm += N;
+    }
+    acc_done_draw += done + ((done & ~win) << 16);
+    acc_black_white += (win & ~side) + ((win & side) << 16);
+    len_sum += p.done ? (e.meta >> 1) : 0u;
+    if (p.done) env_clear<NW>(e);  // env.reset(nonzero(done)) :34-44
+  }
+};
+
+template <int NW, int CN, int CK, bool RECORD, int ACT>
+__global__ void __launch_bounds__(64)
+k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed, uint64_t step0,
+                 int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, unsigned long long* stats,
+                 void* act_log) {
+  // one full wave of 64 envs per workgroup: half-filled waves were measured and are slower
+  // (gfx950 does not skip the idle half of a wave64), see DESIGN.md
+  __shared__ unsigned int lds_stats[MNK_STATS_COUNTERS];
+  if (threadIdx.x < MNK_STATS_COUNTERS) lds_stats[threadIdx.x] = 0u;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) {
+    RolloutLane<NW, CN, CK, RECORD, ACT> L(g, N, i, rec_planes, rec_meta, act_log);
+    env_load<NW, L.EXACT>(L.e, planes, meta, N, g.W, i);
+    const uint64_t env = (uint64_t)(env_id0 + i);
+    int t = 0;
+    uint64_t step = step0;
+    if (step & 3) {  // head: finish the Philox block the previous launch stopped in
+      const Philox4 blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
+      for (; t < T && (step & 3); ++t, ++step) L.ply(philox_word(blk, (uint32_t)(step & 3)), (int)(step & 3));
+    }
+    for (; t + 4 <= T; t += 4, step += 4) {
+      const Philox4 blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
+      L.ply(blk.v[0], 0);
+      L.ply(blk.v[1], 1);
+      L.ply(blk.v[2], 2);
+      L.ply(blk.v[3], 3);
+    }
+    if (t < T) {
+      const Philox4 blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
+      for (uint32_t j = 0; t < T; ++t, ++j) L.ply(philox_word(blk, j), (int)j);
+    }
+    if (ACT && (T & 3)) L.log_flush();  // T not a multiple of 4: the last word is partly filled
+    env_store<NW, L.EXACT>(L.e, planes, meta, N, g.W, i);
+    if (stats) {
+      if (L.acc_done_draw & 0xFFFFu) atomicAdd(&lds_stats[0], L.acc_done_draw & 0xFFFFu);
+      if (L.acc_black_white & 0xFFFFu) atomicAdd(&lds_stats[1], L.acc_black_white & 0xFFFFu);
+      if (L.acc_black_white >> 16) atomicAdd(&lds_stats[2], L.acc_black_white >> 16);
+      if (L.acc_done_draw >> 16) atomicAdd(&lds_stats[3], L.acc_done_draw >> 16);
+      if (L.len_sum) atomicAdd(&lds_stats[4], L.len_sum);
+    }
+  }
+  __syncthreads();
+  // one global atomic per counter per wave, spread over MNK_STATS_REPLICAS cache lines: thousands
+  // of adds on five addresses would serialise at ~11 ns each (measured: 56 us per launch)
+  if (stats && threadIdx.x < MNK_STATS_COUNTERS && lds_stats[threadIdx.x])
+    atomicAdd(&stats[(size_t)(blockIdx.x % MNK_STATS_REPLICAS) * MNK_STATS_STRIDE + threadIdx.x],
+              (unsigned long long)lds_stats[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------ replay of an action log
+// The receiving side of the multi-GPU exchange: a shard's rollout is fully determined by its
+// chunk-start state and its action log (1-2 bytes per ply), so that is what crosses xGMI; this
+// kernel re-plays the log and rebuilds the full packed records, bit-identical to the sender's.
+template <int NW, int CN, int CK, bool RECORD>
+__global__ void __launch_bounds__(64)
+k_replay_actions(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, const void* act_log, int act_bytes,
+                 uint64_t* rec_planes, uint32_t* rec_meta, int32_t* err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  RolloutLane<NW, CN, CK, RECORD> L(g, N, i, rec_planes, rec_meta, nullptr);
+  env_load<NW, L.EXACT>(L.e, planes, meta, N, g.W, i);
+  const uint32_t* q32 = (const uint32_t*)act_log;
+  const uint64_t* q64 = (const uint64_t*)act_log;
+  bool bad = false;
+  uint64_t quad = 0;
+  for (int t = 0; t < T; ++t) {
+    if ((t & 3) == 0) quad = act_bytes == 1 ? (uint64_t)q32[(int64_t)(t >> 2) * N + i] : q64[(int64_t)(t >> 2) * N + i];
+    int a = act_bytes == 1 ? (int)(quad & 0xFFu) : (int)(quad & 0xFFFFu);
+    quad >>= 8 * act_bytes;
+    if (a >= g.C) { bad = true; a = 0; }  // a log we did not write: flag it, keep the wave in step
+    L.ply_action(a);
+  }
+  if (bad) mnk_report(err, MNK_ERR_ACTION_RANGE, i);
+  env_store<NW, L.EXACT>(L.e, planes, meta, N, g.W, i);
+}
+
+// ================================================================== C ABI
+extern "C" {
+
+int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, int T, uint64_t seed,
+                       uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
+                       void* act_log, int act_bytes, void* stream) {
+  MnkGeom g;
+  int rc = mnk_check_geom(m, n, k, &g);
+  if (rc != MNK_OK) return rc;
+  if (!planes || !meta || N < 0 || T < 0 || T > 65535 || (!rec_planes != !rec_meta)) return MNK_EINVAL;
+  if (act_log && !(act_bytes == 2 || (act_bytes == 1 && g.C <= 256))) return MNK_EINVAL;
+  if (act_log && (step0 & 3)) return MNK_EINVAL;  // log words hold plies 4q..4q+3 of the Philox step counter
+  if (!act_log) act_bytes = 0;
+  if (N == 0 || T == 0) return MNK_OK;
+  const int B = 64;
+  const dim3 grid((unsigned)((N + B - 1) / B));
+#define MNK_ROLLOUT(REC, ACTB)                                                                                   \
+  MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NW, CN, CK, REC, ACTB>), grid, dim3(B), 0, \
+                                     (hipStream_t)stream, g, planes, meta, N, T, seed, step0, env_id0,           \
+                                     rec_planes, rec_meta, (unsigned long long*)stats, act_log))
+  const bool rec = rec_planes && rec_meta;
+  if (rec && act_bytes == 0) MNK_ROLLOUT(true, 0);
+  else if (rec && act_bytes == 1) MNK_ROLLOUT(true, 1);
+  else if (rec && act_bytes == 2) MNK_ROLLOUT(true, 2);
+  else if (act_bytes == 1) MNK_ROLLOUT(false, 1);
+  else if (act_bytes == 2) MNK_ROLLOUT(false, 2);
+  else MNK_ROLLOUT(false, 0);
+#undef MNK_ROLLOUT
+  return mnk_launch_status("rollout_random");
+}
+
+int mnk_replay_actions(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, int T, const void* act_log,
+                       int act_bytes, uint64_t* rec_planes, uint32_t* rec_meta, int32_t* err, void* stream) {
+  MnkGeom g;
+  int rc = mnk_check_geom(m, n, k, &g);
+  if (rc != MNK_OK) return rc;
+  if (!planes || !meta || !act_log || N < 0 || T < 0 || (!rec_planes != !rec_meta)) return MNK_EINVAL;
+  if (!(act_bytes == 2 || (act_bytes == 1 && g.C <= 256))) return MNK_EINVAL;
+  if (N == 0 || T == 0) return MNK_OK;
+  const int B = 64;
+  const dim3 grid((unsigned)((N + B - 1) / B));
+  if (rec_planes && rec_meta)
+    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_replay_actions<NW, CN, CK, true>), grid, dim3(B), 0,
+                                       (hipStream_t)stream, g, planes, meta, N, T, act_log, act_bytes, rec_planes,
+                                       rec_meta, err));
+  else
+    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_replay_actions<NW, CN, CK, false>), grid, dim3(B), 0,
+                                       (hipStream_t)stream, g, planes, meta, N, T, act_log, act_bytes, nullptr,
+                                       nullptr, err));
+  return mnk_launch_status("replay_actions");
+}
+
+}  // extern "C"

@@ -32,7 +32,7 @@ import mnk_hip
 class RolloutRecords:
     planes: torch.Tensor  # int64 (u64 bits) [T, 2, W, N]
     meta: torch.Tensor    # int32 (u32 bits) [T, N]
-    act: Optional[torch.Tensor] = None    # action log uint8 / int16 [T, N] (when logging was on)
+    act: Optional[torch.Tensor] = None    # action log, 4 plies per word: int32 / int64 [ceil(T/4), N] (when logging was on)
     meta0: Optional[torch.Tensor] = None  # env meta words at the start of the chunk, int32 [N]
 
     @property
@@ -79,7 +79,8 @@ class RandomRollout:
             meta=torch.empty((steps, env.num_envs), dtype=torch.int32, device=env._dev),
         )
         if log_actions:
-            rec.act = torch.empty((steps, env.num_envs), dtype=action_log_dtype(env.max_moves), device=env._dev)
+            rec.act = torch.empty(((steps + 3) // 4, env.num_envs), dtype=action_log_dtype(env.max_moves),
+                                  device=env._dev)
             rec.meta0 = torch.empty(env.num_envs, dtype=torch.int32, device=env._dev)
         return rec
 
@@ -99,15 +100,23 @@ class RandomRollout:
             mnk_hip.call("mnk_rollout_random", mnk_hip.ptr(env._planes), mnk_hip.ptr(env._meta), env.num_envs,
                          env.m, env.n, env.k, steps, self.seed, self.step, self.env_id0,
                          mnk_hip.ptr(out.planes) if record else None, mnk_hip.ptr(out.meta) if record else None,
-                         mnk_hip.ptr(self._stats), mnk_hip.ptr(act), act.element_size() if act is not None else 0,
+                         mnk_hip.ptr(self._stats), mnk_hip.ptr(act), act.element_size() // 4 if act is not None else 0,
                          env._stream())
         self.step += steps
         return out if record else None
 
 
 def action_log_dtype(num_actions: int):
-    """one byte per ply while the board has at most 256 cells, two beyond"""
-    return torch.uint8 if num_actions <= 256 else torch.int16
+    """The log packs four plies per word: int32 words (one byte per action) while the board has at most
+    256 cells, int64 words (16 bits per action) beyond."""
+    return torch.int32 if num_actions <= 256 else torch.int64
+
+
+def unpack_action_log(act: torch.Tensor, steps: int) -> torch.Tensor:
+    """[ceil(T/4), N] packed log -> int64 actions [T, N]"""
+    bits = 8 if act.dtype == torch.int32 else 16
+    fields = [(act >> (bits * j)) & ((1 << bits) - 1) for j in range(4)]
+    return torch.stack(fields, dim=1).reshape(-1, act.shape[1])[:steps].to(torch.int64)
 
 
 @dataclass
@@ -115,7 +124,8 @@ class GatheredLogs:
     """What ``gather_action_logs`` leaves on every rank: per shard r the chunk-start state and the log."""
     planes0: torch.Tensor  # int64 [world, 2, W, N]
     meta0: torch.Tensor    # int32 [world, N]
-    act: torch.Tensor      # uint8 / int16 [world, T, N]
+    act: torch.Tensor      # int32 / int64 [world, ceil(T/4), N]: four plies per word
+    steps: int = 0         # T
 
 
 def gather_action_logs(rec: RolloutRecords, group=None, out: Optional[GatheredLogs] = None) -> GatheredLogs:
@@ -129,7 +139,8 @@ def gather_action_logs(rec: RolloutRecords, group=None, out: Optional[GatheredLo
     if out is None:
         out = GatheredLogs(planes0=torch.empty((world, two, w, n), dtype=torch.int64, device=dev),
                            meta0=torch.empty((world, n), dtype=torch.int32, device=dev),
-                           act=torch.empty((world, t, n), dtype=rec.act.dtype, device=dev))
+                           act=torch.empty((world,) + tuple(rec.act.shape), dtype=rec.act.dtype, device=dev))
+    out.steps = t
     dist.all_gather_into_tensor(out.planes0.view(-1), rec.planes[0].reshape(-1), group=group)
     dist.all_gather_into_tensor(out.meta0.view(-1), rec.meta0.view(-1), group=group)
     dist.all_gather_into_tensor(out.act.view(-1), rec.act.view(-1), group=group)
@@ -141,7 +152,8 @@ def replay_shard(logs: GatheredLogs, shard: int, m: int, n: int, k: int, err: Op
     """Rebuilds shard ``shard``'s full packed records from its gathered state + action log
     (``mnk_replay_actions``, one launch); bit-identical to what the owning rank recorded."""
     act = logs.act[shard]
-    t, nenv = act.shape
+    t, nenv = logs.steps, act.shape[1]
+    assert act.shape[0] == (t + 3) // 4, "GatheredLogs.steps does not match the packed log"
     dev = act.device
     planes = logs.planes0[shard].clone()
     meta = logs.meta0[shard].clone()
@@ -153,7 +165,7 @@ def replay_shard(logs: GatheredLogs, shard: int, m: int, n: int, k: int, err: Op
         err = torch.zeros(2, dtype=torch.int32, device=dev)
     if t and nenv:
         mnk_hip.call("mnk_replay_actions", mnk_hip.ptr(planes), mnk_hip.ptr(meta), nenv, m, n, k, t,
-                     mnk_hip.ptr(act), act.element_size(), mnk_hip.ptr(out.planes), mnk_hip.ptr(out.meta),
+                     mnk_hip.ptr(act), act.element_size() // 4, mnk_hip.ptr(out.planes), mnk_hip.ptr(out.meta),
                      mnk_hip.ptr(err), mnk_hip.stream_ptr(dev))
     return out
 

@@ -41,12 +41,18 @@ def _worker(rank, world, port, m, n, k, nenv, steps, seed, out_dir):
         assert full.meta.shape == (steps, world * nenv)
         # the compact exchange format: chunk-start state + action log
         from selfplay.random_rollout import gather_action_logs
-        rec.act = torch.from_numpy((meta & 0xFFFF).astype(np.uint8))
+        from selfplay.random_rollout import unpack_action_log
+        acts = (meta & 0xFFFF).astype(np.int64)
+        pad = np.zeros(((-steps) % 4, nenv), dtype=np.int64)
+        quads = np.concatenate([acts, pad]).reshape(-1, 4, nenv)
+        rec.act = torch.from_numpy((quads[:, 0] | quads[:, 1] << 8 | quads[:, 2] << 16 | quads[:, 3] << 24).astype(np.int32))
         rec.meta0 = torch.zeros(nenv, dtype=torch.int32)  # every env starts from reset
         logs = gather_action_logs(rec)
-        assert logs.act.shape == (world, steps, nenv) and logs.planes0.shape[0] == world
+        assert logs.act.shape == (world, (steps + 3) // 4, nenv) and logs.planes0.shape[0] == world and logs.steps == steps
         assert torch.equal(logs.act[rank], rec.act) and torch.equal(logs.planes0[rank], rec.planes[0])
-        assert torch.equal((full.meta & 0xFFFF).view(steps, world, nenv).permute(1, 0, 2).to(torch.uint8), logs.act)
+        for r in range(world):
+            assert torch.equal(unpack_action_log(logs.act[r], steps),
+                               (full.meta[:, r * nenv:(r + 1) * nenv] & 0xFFFF).to(torch.int64))
         totals = torch.from_numpy(stats)
         dist.all_reduce(totals)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), planes=full.planes.numpy(), meta=full.meta.numpy(),

@@ -226,12 +226,12 @@ def test_full_size_rollout_properties(hip):
 
 
 @pytest.mark.parametrize("m,n,k,nenv,steps", [(3, 3, 3, 70, 40), (9, 9, 5, 200, 130), (19, 19, 5, 65, 90),
-                                              (13, 13, 5, 5, 150), (7, 9, 7, 64, 80)])
+                                              (13, 13, 5, 5, 150), (7, 9, 7, 64, 81), (9, 9, 5, 64, 6)])
 def test_action_log_replay_rebuilds_the_records(hip, m, n, k, nenv, steps):
     """The multi-GPU exchange format: chunk-start state + action log (1-2 B per ply).
     mnk_replay_actions on the log == the records the rollout wrote (bit for bit) == the oracle's
     replay of the same log; a second chunk checks that the state carried over."""
-    from selfplay.random_rollout import GatheredLogs, replay_shard
+    from selfplay.random_rollout import GatheredLogs, replay_shard, unpack_action_log
 
     env = hip.Env(m, n, k, nenv, device=DEV)
     roll = hip.Rollout(env, seed=21, env_id0=7)
@@ -239,13 +239,15 @@ def test_action_log_replay_rebuilds_the_records(hip, m, n, k, nenv, steps):
     for chunk in range(2):
         rec = roll.alloc(steps, log_actions=True)
         roll.run(steps, out=rec)
-        assert rec.act.dtype == (torch.uint8 if m * n <= 256 else torch.int16)
-        assert torch.equal(rec.act.to(torch.int64), rec.actions())
+        assert rec.act.dtype == (torch.int32 if m * n <= 256 else torch.int64)
+        assert rec.act.shape == ((steps + 3) // 4, nenv)
+        actions = unpack_action_log(rec.act, steps)
+        assert torch.equal(actions, rec.actions())
         logs = GatheredLogs(planes0=rec.planes[0].unsqueeze(0).clone(), meta0=rec.meta0.unsqueeze(0).clone(),
-                            act=rec.act.unsqueeze(0).clone())
+                            act=rec.act.unsqueeze(0).clone(), steps=steps)
         again = replay_shard(logs, 0, m, n, k)
         assert torch.equal(again.planes, rec.planes) and torch.equal(again.meta, rec.meta)
-        planes, meta = oracle_replay(ora, rec.act.cpu().numpy())
+        planes, meta = oracle_replay(ora, actions.cpu().numpy())
         assert np.array_equal(rec.planes.cpu().numpy().view(np.uint64), planes)
         assert np.array_equal(rec.meta.cpu().numpy().view(np.uint32), meta)
 
@@ -255,7 +257,7 @@ def test_replay_flags_a_foreign_log(hip):
 
     env = hip.Env(3, 3, 3, 8, device=DEV)
     logs = GatheredLogs(planes0=env._planes.unsqueeze(0).clone(), meta0=env._meta.unsqueeze(0).clone(),
-                        act=torch.full((1, 4, 8), 200, dtype=torch.uint8, device=DEV))
+                        act=torch.full((1, 1, 8), 200, dtype=torch.int32, device=DEV), steps=4)
     err = torch.zeros(2, dtype=torch.int32, device=DEV)
     replay_shard(logs, 0, 3, 3, 3, err=err)
     assert err[0].item() == hip.lib.ERR_ACTION_RANGE
