@@ -317,6 +317,9 @@ def main():
     env.reset()
     roll = RandomRollout(env, seed=args.seed, env_id0=rank * nenv)
     mode = args.gather if world > 1 else "none"
+    if mode == "actions":  # a log word holds plies 4q..4q+3: chunks (and so the warm-up) end on multiples of 4
+        chunk = args.chunk = max(4, chunk - chunk % 4)
+        args.warmup += (-args.warmup) % 4
     bufs = [roll.alloc(chunk, log_actions=(mode == "actions")) for _ in range(2)]
     gathered = side = None
     if mode != "none":

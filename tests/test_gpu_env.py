@@ -236,7 +236,8 @@ def test_action_log_replay_rebuilds_the_records(hip, m, n, k, nenv, steps):
     env = hip.Env(m, n, k, nenv, device=DEV)
     roll = hip.Rollout(env, seed=21, env_id0=7)
     ora = OracleVectorEnv(m, n, k, nenv)
-    for chunk in range(2):
+    # with a log every chunk but the last is a multiple of four plies (one log word = plies 4q..4q+3)
+    for steps in (steps - steps % 4, steps):
         rec = roll.alloc(steps, log_actions=True)
         roll.run(steps, out=rec)
         assert rec.act.dtype == (torch.int32 if m * n <= 256 else torch.int64)
@@ -250,6 +251,16 @@ def test_action_log_replay_rebuilds_the_records(hip, m, n, k, nenv, steps):
         planes, meta = oracle_replay(ora, actions.cpu().numpy())
         assert np.array_equal(rec.planes.cpu().numpy().view(np.uint64), planes)
         assert np.array_equal(rec.meta.cpu().numpy().view(np.uint32), meta)
+
+
+def test_action_log_needs_aligned_chunks(hip):
+    env = hip.Env(3, 3, 3, 8, device=DEV)
+    roll = hip.Rollout(env, seed=1)
+    roll.run(6, out=roll.alloc(6, log_actions=True))      # fine: starts at step 0
+    with pytest.raises(hip.lib.MnkHipError):
+        roll.run(4, out=roll.alloc(4, log_actions=True))  # would start at step 6
+    roll.run(2)                                            # without a log any step is fine
+    roll.run(4, out=roll.alloc(4, log_actions=True))      # step 8 again
 
 
 def test_replay_flags_a_foreign_log(hip):
