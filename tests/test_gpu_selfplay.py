@@ -381,3 +381,47 @@ def test_rollout_buffer_dropin(hip):
         buf.add(obs, act, rew, val, lp, done, mask)
     buf.reset()
     assert buf.ptr == 0 and float(buf.rewards.abs().sum()) == 0.0
+
+
+def test_full_size_selfplay_properties(hip):
+    """BASELINE.json size (9x9x5, 65 536 envs), fused self-play step with the random opponent: properties
+    that need no oracle run.  Every step: rewards in {-1, 0, +1} and non-zero only on terminated envs; the
+    returned view is the env state seen from the agent's side with mask == free cells; a terminated env is
+    reset by the next step (reward 0, not terminated, at most one opponent stone on the board); stone counts
+    of the two sides never differ by more than one; and the long-run outcome of random-vs-random play is
+    symmetric between agent and opponent."""
+    m, n, k, nenv = 9, 9, 5, 65536
+    env = hip.Env(m, n, k, nenv, device=DEV)
+    wrap = hip.Wrapper(env, seed=4)
+    wrap.set_opponent(hip.policy.RandomPolicy(m * n))
+    agent = hip.policy.RandomPolicy(m * n, seed=8)
+    obs, _ = wrap.reset()
+    wins = losses = draws = 0
+    prev_term = torch.zeros(nenv, dtype=torch.bool, device=DEV)
+    for t in range(120):
+        acts = agent.act(obs)
+        assert bool(torch.gather(obs["action_mask"], 1, acts.unsqueeze(1)).all())
+        obs, rew, term, trunc, _ = wrap.step(acts)
+        assert not bool(trunc.any())
+        assert bool(((rew == 0) | (rew == 1) | (rew == -1)).all()) and not bool((rew != 0)[~term].any())
+        assert torch.equal(wrap.pending_resets, term)
+        # freshly reset envs: no reward, not terminated, board holds 0 or 1 stones (the opponent's opening)
+        fresh = prev_term
+        assert not bool(term[fresh].any()) and not bool((rew[fresh] != 0).any())
+        stones = obs["observation"].sum(dim=(2, 3))
+        assert bool((stones[fresh, 0] == 0).all()) and bool((stones[fresh, 1] <= 1).all())
+        # the view is the state from the agent's side
+        dense = env.boards[...]
+        flip = wrap.agent_side == 1
+        want = torch.where(flip.view(-1, 1, 1, 1), dense.flip(1), dense)
+        assert torch.equal(obs["observation"], want)
+        free = (dense.sum(dim=1) == 0).reshape(nenv, -1)
+        free[free.sum(dim=1) == 0, 0] = True
+        assert torch.equal(obs["action_mask"], free)
+        assert bool((stones[:, 0] - stones[:, 1]).abs().max() <= 1)
+        wins += int((rew == 1).sum()); losses += int((rew == -1).sum()); draws += int((term & (rew == 0)).sum())
+        prev_term = term
+    games = wins + losses + draws
+    assert games > 100000
+    assert abs(wins - losses) / games < 0.02      # same policy on both sides, sides drawn uniformly
+    assert draws / games < 0.01
