@@ -272,3 +272,37 @@ def test_replay_flags_a_foreign_log(hip):
     err = torch.zeros(2, dtype=torch.int32, device=DEV)
     replay_shard(logs, 0, 3, 3, 3, err=err)
     assert err[0].item() == hip.lib.ERR_ACTION_RANGE
+
+
+def _fuzz_geometries(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < count:
+        m, n = int(rng.integers(2, 23)), int(rng.integers(2, 23))
+        k = int(rng.integers(1, min(m, n) + 1))
+        if m * (n + 1) <= 512:
+            out.append((m, n, k))
+    return out
+
+
+@pytest.mark.parametrize("m,n,k", _fuzz_geometries(24, seed=2026) + [(22, 22, 10), (9, 9, 4), (9, 9, 9), (2, 22, 2),
+                                                                      (22, 2, 2), (15, 15, 5), (12, 9, 5)])
+def test_generic_geometries_match_oracle(hip, m, n, k):
+    """Boards outside the compile-time specialisations (and odd ones inside them): the generic kernels with
+    run-time shifts -- including shift amounts >= 32 and k up to 10 -- against the oracle: a fused rollout
+    (records, statistics, final state) and an API-level step with observation and mask, bit for bit."""
+    nenv, steps = 67, 3 * max(m, n)
+    env = hip.Env(m, n, k, nenv, device=DEV)
+    roll = hip.Rollout(env, seed=m * 1000 + n * 10 + k)
+    ora = OracleVectorEnv(m, n, k, nenv)
+    rec = roll.run(steps)
+    planes, meta, stats = random_rollout(ora, seed=m * 1000 + n * 10 + k, step0=0, steps=steps)
+    assert np.array_equal(rec.planes.cpu().numpy().view(np.uint64), planes)
+    assert np.array_equal(rec.meta.cpu().numpy().view(np.uint32), meta)
+    assert np.array_equal(roll.stats.cpu().numpy(), stats)
+    acts = torch.from_numpy(np.random.default_rng(k).integers(-m * n, m * n, nenv))
+    o1, r1, d1 = env.step(acts.to(DEV))
+    o2, r2, d2 = ora.step(acts)
+    assert torch.equal(o1["observation"].cpu(), o2["observation"]) and torch.equal(o1["action_mask"].cpu(), o2["action_mask"])
+    assert torch.equal(r1.cpu(), r2) and torch.equal(d1.cpu(), d2)
+    assert torch.equal(env.move_counts.cpu(), ora.move_counts) and torch.equal(env.current_player.cpu(), ora.current_player)
