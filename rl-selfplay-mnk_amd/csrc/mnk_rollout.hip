@@ -17,7 +17,11 @@ template <int NW, int CN, int CK, bool RECORD, int ACT = 0>
 struct RolloutLane {
   static constexpr bool EXACT = CN != 0;
   const MnkGeom& g;
-  MnkEnv<NW> e;
+  // The env in "mover first" form: cur = plane of the side to move, oth = the other plane.  A ply then ORs
+  // one bit into cur, scans cur and swaps the two names (free: the loop is unrolled) -- no per-word selects
+  // on the side bit as with (black, white) planes.  Black/white order is restored only where memory sees it.
+  uint32_t cur[NW], oth[NW];
+  uint32_t side, moves;
   int64_t N;
   // this lane's cursors into the record arrays; they advance by one ply's stride after every ply
   uint64_t* rp = nullptr;  // rec_planes[t][0][0][i]
@@ -35,6 +39,37 @@ struct RolloutLane {
     if (ACT) ra = (uint8_t*)act_log + i * 4 * ACT;
   }
 
+  __device__ __forceinline__ void load(const uint64_t* planes, const uint32_t* meta, int64_t i) {
+    uint32_t p0[NW], p1[NW];
+    plane_load<NW, EXACT>(p0, planes, N, g.W, i);
+    plane_load<NW, EXACT>(p1, planes + (int64_t)g.W * N, N, g.W, i);
+    const uint32_t mw = meta[i];
+    side = mw & 1u;
+    moves = mw >> 1;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      cur[w] = side ? p1[w] : p0[w];
+      oth[w] = side ? p0[w] : p1[w];
+    }
+  }
+
+  // (black, white) planes of the current position to memory at `dst`
+  __device__ __forceinline__ void store_planes(uint64_t* dst, int64_t i) const {
+    uint32_t p0[NW], p1[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      p0[w] = side ? oth[w] : cur[w];
+      p1[w] = side ? cur[w] : oth[w];
+    }
+    plane_store<NW, EXACT>(p0, dst, N, g.W, i);
+    plane_store<NW, EXACT>(p1, dst + (int64_t)g.W * N, N, g.W, i);
+  }
+
+  __device__ __forceinline__ void store(uint64_t* planes, uint32_t* meta, int64_t i) const {
+    store_planes(planes, i);
+    meta[i] = (moves << 1) | side;
+  }
+
   __device__ __forceinline__ void log_flush() {
     if (ACT == 1) *(uint32_t*)ra = (uint32_t)quad;
     if (ACT == 2) *(uint64_t*)ra = quad;
@@ -42,35 +77,68 @@ struct RolloutLane {
     quad = 0;
   }
 
+  // uniform legal cell from one u32 (oracle/philox.py pick_legal; selfplay/policy.py:18-29); returns the
+  // bit index of the cell, the action goes to `action`
+  __device__ __forceinline__ uint32_t pick(uint32_t x, int& action) const {
+    uint32_t legal[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) legal[w] = ~(cur[w] | oth[w]) & g.valid[w];
+    const int nl = bs_popcount<NW>(legal);
+    const int r = (int)__umulhi(x, (uint32_t)(nl ? nl : g.C));
+    const uint32_t bit = (uint32_t)bs_select<NW>(legal, r);
+    const uint32_t cell = bit - (CN ? bit / (uint32_t)(CN + 1) : mnk_div(bit, g.magic_stride));
+    action = nl ? (int)cell : r;  // full board (poked states only): any cell, like RandomPolicy's 1e-8 guard
+    // the bit of that cell (the select's result is meaningless on a full board)
+    return nl ? bit : (uint32_t)r + (CN ? (uint32_t)r / (uint32_t)CN : mnk_div((uint32_t)r, g.magic_n));
+  }
+
   // field = position of this ply inside its group of four (= step & 3; a compile-time constant in
   // the unrolled main loop, so the log costs one shift-or per ply and one wide store per four)
   __device__ __forceinline__ void ply(uint32_t x, int field) {
-    const int a = env_pick_legal<NW, CN>(g, e, x);
+    int a;
+    const uint32_t bit = pick(x, a);
     if (ACT) {
       quad |= (uint64_t)(uint32_t)a << (8 * ACT * field);
       if (field == 3) log_flush();
     }
-    ply_action(a);
+    ply_bit(a, bit);
   }
 
-  // one ply with a known-good action (from the sampler, or from an action log the sampler wrote)
+  // one ply with a known-good action (from an action log the sampler wrote)
   __device__ __forceinline__ void ply_action(int a) {
+    const uint32_t ua = (uint32_t)a;
+    ply_bit(a, ua + (CN ? ua / (uint32_t)CN : mnk_div(ua, g.magic_n)));
+  }
+
+  // env/torch_vector_mnk_env.py:60-84 for the mover, then env.reset(nonzero(done)) :34-44
+  __device__ __forceinline__ void ply_bit(int a, uint32_t bit) {
     if (RECORD) {
-      plane_store<NW, EXACT>(e.p[0], rp, N, g.W, 0);
-      plane_store<NW, EXACT>(e.p[1], rp + (int64_t)g.W * N, N, g.W, 0);
+      store_planes(rp, 0);
       rp += (int64_t)2 * g.W * N;
     }
-    const uint32_t side = e.meta & 1u;
-    const MnkPly p = env_play<NW, CN, CK, true>(g, e, a, false);
-    const uint32_t win = p.win ? 1u : 0u, done = p.done ? 1u : 0u;
+    const int wsel = (int)(bit >> 5);
+    const uint32_t one = 1u << (bit & 31u);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) cur[w] |= (w == wsel) ? one : 0u;   // :68
+    ++moves;                                                          // :69
+    const uint32_t win = mnk_plane_wins<NW, CN, CK>(g, cur) ? 1u : 0u;  // :71
+    const uint32_t done = win | (moves >= (uint32_t)g.C ? 1u : 0u);   // :72-73
     if (RECORD) {
       *rm = (uint32_t)a | (win << MNK_REC_REWARD_SHIFT) | (done << MNK_REC_DONE_BIT) | (side << MNK_REC_SIDE_BIT);
       rm += N;
     }
     acc_done_draw += done + ((done & ~win) << 16);
     acc_black_white += (win & ~side) + ((win & side) << 16);
-    len_sum += p.done ? (e.meta >> 1) : 0u;
-    if (p.done) env_clear<NW>(e);  // env.reset(nonzero(done)) :34-44
+    len_sum += done ? moves : 0u;
+    // the other side is to move (:82) -- or a fresh game
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const uint32_t c = cur[w];
+      cur[w] = done ? 0u : oth[w];
+      oth[w] = done ? 0u : c;
+    }
+    side = done ? 0u : (side ^ 1u);
+    moves = done ? 0u : moves;
   }
 };
 
@@ -87,7 +155,7 @@ k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, 
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) {
     RolloutLane<NW, CN, CK, RECORD, ACT> L(g, N, i, rec_planes, rec_meta, act_log);
-    env_load<NW, L.EXACT>(L.e, planes, meta, N, g.W, i);
+    L.load(planes, meta, i);
     const uint64_t env = (uint64_t)(env_id0 + i);
     int t = 0;
     uint64_t step = step0;
@@ -107,7 +175,7 @@ k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, 
       for (uint32_t j = 0; t < T; ++t, ++j) L.ply(philox_word(blk, j), (int)j);
     }
     if (ACT && (T & 3)) L.log_flush();  // T not a multiple of 4: the last word is partly filled
-    env_store<NW, L.EXACT>(L.e, planes, meta, N, g.W, i);
+    L.store(planes, meta, i);
     if (stats) {
       if (L.acc_done_draw & 0xFFFFu) atomicAdd(&lds_stats[0], L.acc_done_draw & 0xFFFFu);
       if (L.acc_black_white & 0xFFFFu) atomicAdd(&lds_stats[1], L.acc_black_white & 0xFFFFu);
@@ -313,7 +381,7 @@ k_replay_actions(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, 
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   RolloutLane<NW, CN, CK, RECORD> L(g, N, i, rec_planes, rec_meta, nullptr);
-  env_load<NW, L.EXACT>(L.e, planes, meta, N, g.W, i);
+  L.load(planes, meta, i);
   const uint32_t* q32 = (const uint32_t*)act_log;
   const uint64_t* q64 = (const uint64_t*)act_log;
   bool bad = false;
@@ -326,7 +394,7 @@ k_replay_actions(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, 
     L.ply_action(a);
   }
   if (bad) mnk_report(err, MNK_ERR_ACTION_RANGE, i);
-  env_store<NW, L.EXACT>(L.e, planes, meta, N, g.W, i);
+  L.store(planes, meta, i);
 }
 
 // ================================================================== C ABI
