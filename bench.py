@@ -2,10 +2,11 @@
 """bench.py -- random-policy rollout throughput of the MNK self-play path on MI355X.
 
 Metric (BASELINE.json): env-steps/sec, 9x9x5, 65 536 parallel envs per GPU, random-policy
-rollout.  A "step" is one ply on every env of the batch: uniform legal move (RandomPolicy),
-place stone, 4-direction win scan, reward/done, restart of finished games, packed record
-written to HBM -- executed by the fused kernel ``mnk_rollout_random`` in chunks of
-``--chunk`` plies per launch.  With --gpus N > 1 the env axis is sharded (65 536 envs per
+rollout.  A bench "step" is one pass of the hot path over the batch = ONE launch of the fused
+kernel ``mnk_rollout_random``: ``--chunk`` plies (default 256 = the reference's n_steps) on every
+env -- per ply: uniform legal move (RandomPolicy), place stone, 4-direction win scan, reward/done,
+restart of finished games, packed record written to HBM.  ``value`` is env-steps (plies x envs)
+per second.  With --gpus N > 1 the env axis is sharded (65 536 envs per
 rank, global env ids key the RNG) and every chunk is all-gathered over RCCL on a side stream
 while the next chunk runs -- by default as chunk-start state + action log (1 B per env-step at
 9x9, rebuilt into full records on demand by mnk_replay_actions), with --gather records as the
@@ -43,8 +44,9 @@ PMC_TRAFFIC = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4096)
-    ap.add_argument("--warmup", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=16, help="timed launches of the rollout kernel (chunk plies each)")
+    ap.add_argument("--warmup", type=int, default=2,
+                    help="untimed launches first (2 x 256 plies: the boards reach their stationary fill)")
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--board", type=str, default="9x9x5")
     ap.add_argument("--chunk", type=int, default=256,
@@ -242,7 +244,7 @@ def selfplay_mode(args):
         # plies played this step = growth of the move counters (resets restart them at 0 or 1)
         state["plies"] += torch.clamp((env._meta >> 1) - before, min=0).sum()
 
-    steps, warm = min(args.steps, 256), min(args.warmup, 64)
+    steps, warm = min(args.steps * 16, 256), 64  # agent-steps here, not kernel launches
     for t in range(warm):
         step(t)
     state["plies"].zero_()
@@ -319,7 +321,6 @@ def main():
     mode = args.gather if world > 1 else "none"
     if mode == "actions":  # a log word holds plies 4q..4q+3: chunks (and so the warm-up) end on multiples of 4
         chunk = args.chunk = max(4, chunk - chunk % 4)
-        args.warmup += (-args.warmup) % 4
     bufs = [roll.alloc(chunk, log_actions=(mode == "actions")) for _ in range(2)]
     gathered = side = None
     if mode != "none":
@@ -389,11 +390,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    run_steps(args.warmup)
+    run_steps(args.warmup * chunk)
     barrier()
     timing[0] = True
     t0 = time.perf_counter()
-    launches = run_steps(args.steps)
+    launches = run_steps(args.steps * chunk)
+    assert launches == args.steps
     barrier()
     dt = time.perf_counter() - t0
     # time spent inside the rollout kernel only (HIP events on its stream, bracketing each launch)
@@ -403,10 +405,11 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    value = world * nenv * args.steps / dt
+    plies = args.steps * chunk
+    value = world * nenv * plies / dt
     words = env.words
     # roofline of the dominant kernel (mnk_rollout_random): algorithmic bytes per launch / avg launch time
-    plies_per_launch = args.steps / launches
+    plies_per_launch = chunk
     alg_bytes = nenv * (plies_per_launch * record_bytes(words) + 2 * state_bytes(words))
     launch_s = dev_ms * 1e-3 / launches
     achieved = alg_bytes / launch_s / 1e9
@@ -419,6 +422,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt * 1e3 / args.steps,
+        "step_definition": f"one launch of the fused rollout kernel = {chunk} plies on each of {nenv} envs per GPU",
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

@@ -35,7 +35,7 @@ def main():
             print(f"| `{name}` | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | "
                   f"{float(r['Percentage']):.2f} | {r['MinNs']} | {r['MaxNs']} |")
         print()
-    print(f"## counters of `{kern}` (mean per dispatch; separate `--pmc` passes, 1024-ply runs)\n")
+    print(f"## counters of `{kern}` (mean per dispatch; separate `--pmc` passes, 4 timed launches each)\n")
     print("| counter | mean | dispatches |\n|---|---|---|")
     allc = {}
     for sub in ("fetch", "write", "sq"):
