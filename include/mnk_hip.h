@@ -150,14 +150,21 @@ int mnk_selfplay_pre(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, 
 int mnk_selfplay_post(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k,
                       const int64_t* opp_actions, const uint8_t* sp_flags, const int64_t* agent_side,
                       float* rewards, uint8_t* terminated, uint8_t* pending,
-                      float* obs, uint8_t* legal_mask, int32_t* err, void* stream);
+                      float* obs, uint8_t* legal_mask, int32_t* err,
+                      float* ep_return, int32_t* ep_length, int64_t* ep_stats, void* stream);
+/* ep_* (all three or none; NULL = off): device-side episode accounting replacing the host loop of
+ * alg/ppo.py:110-120 (dones.any() + nonzero + tolist, two synchronisations per step).  ep_return f32[N] /
+ * ep_length i32[N] carry the running return and length (agent-steps) of each env's current episode; when
+ * an env terminates its episode is added to ep_stats = int64[MNK_STATS_REPLICAS][MNK_STATS_STRIDE]
+ * {episodes, wins (return > 0), losses (< 0), draws, sum of lengths} and the two running values restart. */
 /* Whole wrapper.step in ONE launch for a uniformly random opponent (RandomPolicy, policy.py:13-29):
  * pre + Philox legal draw (stream OPP) + post. */
 int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k,
                              const int64_t* actions, uint8_t* pending, int64_t* agent_side,
                              const int64_t* forced_side, uint64_t seed, uint64_t step, int64_t env_id0,
                              float* rewards, uint8_t* terminated, float* obs, uint8_t* legal_mask,
-                             int32_t* err, void* stream);
+                             int32_t* err, float* ep_return, int32_t* ep_length, int64_t* ep_stats,
+                             void* stream);
 
 /* ---- the random-policy rollout of BASELINE.json (RandomPolicy.act -> env.step -> env.reset(done)),
  * T plies per env in one launch with the state held in registers.

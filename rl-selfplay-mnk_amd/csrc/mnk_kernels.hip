@@ -147,6 +147,37 @@ k_sample_legal(MnkGeom g, const uint64_t* planes, int64_t N, uint64_t seed, uint
 // selfplay/torch_self_play_wrapper.py:32-67 as fixed-shape masked kernels.  The reference
 // builds nonzero() index lists (two host syncs each) for "envs to reset", "envs to play" and
 // "envs where the opponent replies"; here every env carries those three facts as bits.
+// Optional device-side episode accounting: what alg/ppo.py:110-120 does
+// on the host with dones.any() + nonzero + tolist (two synchronisations per step).  Per env the running
+// return and length (in agent-steps, the autoreset step included, as ppo.py:110-111 counts them); on
+// termination the episode is classified by its return and folded into replicated counters.
+struct MnkEpisodes {
+  float* ep_return;            // [N]
+  int32_t* ep_length;          // [N]
+  unsigned long long* stats;   // [MNK_STATS_REPLICAS][MNK_STATS_STRIDE]: episodes, wins, losses, draws, sum of lengths
+};
+
+__device__ __forceinline__ void mnk_ep_account(const MnkEpisodes& ep, int64_t i, float rew, bool term,
+                                               unsigned int* lds5) {
+  float ret = ep.ep_return[i] + rew;
+  int len = ep.ep_length[i] + 1;
+  if (term) {
+    atomicAdd(&lds5[0], 1u);
+    atomicAdd(&lds5[ret > 0.0f ? 1 : (ret < 0.0f ? 2 : 3)], 1u);
+    atomicAdd(&lds5[4], (unsigned int)len);
+    ret = 0.0f;
+    len = 0;
+  }
+  ep.ep_return[i] = ret;
+  ep.ep_length[i] = len;
+}
+
+__device__ __forceinline__ void mnk_ep_flush(const MnkEpisodes& ep, const unsigned int* lds5) {
+  if (threadIdx.x < MNK_STATS_COUNTERS && lds5[threadIdx.x])
+    atomicAdd(&ep.stats[(size_t)(blockIdx.x % MNK_STATS_REPLICAS) * MNK_STATS_STRIDE + threadIdx.x],
+              (unsigned long long)lds5[threadIdx.x]);
+}
+
 struct SpAgent {
   float reward;
   bool term, was_reset, need_opp;
@@ -218,14 +249,20 @@ template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
 k_selfplay_post(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* opp_actions,
                 const uint8_t* sp_flags, const int64_t* agent_side, float* rewards, uint8_t* terminated,
-                uint8_t* pending, float* obs, uint8_t* legal_mask, int32_t* err, int vec_ok, int envs_per_block) {
+                uint8_t* pending, float* obs, uint8_t* legal_mask, int32_t* err, MnkEpisodes ep, int vec_ok,
+                int envs_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ unsigned int lds_ep[MNK_STATS_COUNTERS];
   const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
   const int64_t env0 = (int64_t)blockIdx.x * B;
   const int64_t i = env0 + tid;
   const bool emit = obs || legal_mask;
   MnkStage st = mnk_stage_carve(lds_raw, g, B);
   if (emit) mnk_stage_tables(st, g, B, tid, NT);
+  if (ep.stats) {
+    if (tid < MNK_STATS_COUNTERS) lds_ep[tid] = 0u;
+    __syncthreads();
+  }
   if (tid < B && i < N) {
     MnkEnv<NW> e;
     env_load<NW>(e, planes, meta, N, g.W, i);
@@ -244,18 +281,20 @@ k_selfplay_post(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const in
       terminated[i] = term ? 1 : 0;
     }
     pending[i] = term ? 1 : 0;  // :65
+    if (ep.stats) mnk_ep_account(ep, i, rew, term, lds_ep);
     if (emit) {
       if (agent_side[i] == 1) mnk_stage_put<NW>(st, g, B, tid, e.p[1], e.p[0], true);  // :104-106
       else mnk_stage_put<NW>(st, g, B, tid, e.p[0], e.p[1], true);
     }
   }
+  if (emit || ep.stats) __syncthreads();
   if (emit) {
-    __syncthreads();
     const int64_t left = N - env0;
     const int nb = left < B ? (int)left : B;
     if (obs) mnk_emit_obs(st, g, nb, obs + env0 * 2 * g.C, vec_ok & 1, tid, NT);
     if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, NT);
   }
+  if (ep.stats) mnk_ep_flush(ep, lds_ep);
 }
 
 // the whole wrapper.step in one launch when the opponent is RandomPolicy (policy.py:13-29)
@@ -264,14 +303,19 @@ __global__ void __launch_bounds__(256)
 k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions,
                        uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
                        uint64_t step, int64_t env_id0, float* rewards, uint8_t* terminated, float* obs,
-                       uint8_t* legal_mask, int32_t* err, int vec_ok, int envs_per_block) {
+                       uint8_t* legal_mask, int32_t* err, MnkEpisodes ep, int vec_ok, int envs_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ unsigned int lds_ep[MNK_STATS_COUNTERS];
   const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
   const int64_t env0 = (int64_t)blockIdx.x * B;
   const int64_t i = env0 + tid;
   const bool emit = obs || legal_mask;
   MnkStage st = mnk_stage_carve(lds_raw, g, B);
   if (emit) mnk_stage_tables(st, g, B, tid, NT);
+  if (ep.stats) {
+    if (tid < MNK_STATS_COUNTERS) lds_ep[tid] = 0u;
+    __syncthreads();
+  }
   if (tid < B && i < N) {
     MnkEnv<NW> e;
     env_load<NW>(e, planes, meta, N, g.W, i);
@@ -292,18 +336,20 @@ k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, c
     rewards[i] = a.reward;
     terminated[i] = a.term ? 1 : 0;
     pending[i] = a.term ? 1 : 0;
+    if (ep.stats) mnk_ep_account(ep, i, a.reward, a.term, lds_ep);
     if (emit) {
       if (side == 1) mnk_stage_put<NW>(st, g, B, tid, e.p[1], e.p[0], true);
       else mnk_stage_put<NW>(st, g, B, tid, e.p[0], e.p[1], true);
     }
   }
+  if (emit || ep.stats) __syncthreads();
   if (emit) {
-    __syncthreads();
     const int64_t left = N - env0;
     const int nb = left < B ? (int)left : B;
     if (obs) mnk_emit_obs(st, g, nb, obs + env0 * 2 * g.C, vec_ok & 1, tid, NT);
     if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, NT);
   }
+  if (ep.stats) mnk_ep_flush(ep, lds_ep);
 }
 
 // ------------------------------------------------------------------ masked categorical head + draw
@@ -627,12 +673,15 @@ int mnk_selfplay_pre(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, 
 
 int mnk_selfplay_post(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const int64_t* opp_actions,
                       const uint8_t* sp_flags, const int64_t* agent_side, float* rewards, uint8_t* terminated,
-                      uint8_t* pending, float* obs, uint8_t* legal_mask, int32_t* err, void* stream) {
+                      uint8_t* pending, float* obs, uint8_t* legal_mask, int32_t* err, float* ep_return,
+                      int32_t* ep_length, int64_t* ep_stats, void* stream) {
   MnkGeom g;
   int rc = mnk_check_geom(m, n, k, &g);
   if (rc != MNK_OK) return rc;
   if (!planes || !meta || !opp_actions || !sp_flags || !agent_side || !rewards || !terminated || !pending || N < 0)
     return MNK_EINVAL;
+  if (ep_stats && (!ep_return || !ep_length)) return MNK_EINVAL;
+  const MnkEpisodes ep = {ep_return, ep_length, (unsigned long long*)ep_stats};
   if (N == 0) return MNK_OK;
   const int B = mnk_block_envs(N);
   const bool emit = obs || legal_mask;
@@ -641,18 +690,21 @@ int mnk_selfplay_post(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n,
   const dim3 grid((unsigned)((N + B - 1) / B));
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_post), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, planes,
                                          meta, N, opp_actions, sp_flags, agent_side, rewards, terminated, pending, obs,
-                                         legal_mask, err, vec_ok, B));
+                                         legal_mask, err, ep, vec_ok, B));
   return mnk_launch_status("selfplay_post");
 }
 
 int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const int64_t* actions,
                              uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
                              uint64_t step, int64_t env_id0, float* rewards, uint8_t* terminated, float* obs,
-                             uint8_t* legal_mask, int32_t* err, void* stream) {
+                             uint8_t* legal_mask, int32_t* err, float* ep_return, int32_t* ep_length,
+                             int64_t* ep_stats, void* stream) {
   MnkGeom g;
   int rc = mnk_check_geom(m, n, k, &g);
   if (rc != MNK_OK) return rc;
   if (!planes || !meta || !actions || !pending || !agent_side || !rewards || !terminated || N < 0) return MNK_EINVAL;
+  if (ep_stats && (!ep_return || !ep_length)) return MNK_EINVAL;
+  const MnkEpisodes ep = {ep_return, ep_length, (unsigned long long*)ep_stats};
   if (N == 0) return MNK_OK;
   const int B = mnk_block_envs(N);
   const bool emit = obs || legal_mask;
@@ -661,7 +713,7 @@ int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m,
   const dim3 grid((unsigned)((N + B - 1) / B));
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_step_random), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g,
                                          planes, meta, N, actions, pending, agent_side, forced_side, seed, step,
-                                         env_id0, rewards, terminated, obs, legal_mask, err, vec_ok, B));
+                                         env_id0, rewards, terminated, obs, legal_mask, err, ep, vec_ok, B));
   return mnk_launch_status("selfplay_step_random");
 }
 

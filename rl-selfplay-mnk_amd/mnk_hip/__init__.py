@@ -42,9 +42,10 @@ SIGNATURES = {
     "mnk_sample_logits": [_vp, _vp, _i64, _i, _u64, _u64, _i64, _i, _vp, _vp, _vp],
     "mnk_selfplay_pre": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _u64, _u64, _i64, _vp, _vp, _vp, _vp, _vp,
                          _vp, _vp],
-    "mnk_selfplay_post": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mnk_selfplay_post": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                          _vp],
     "mnk_selfplay_step_random": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _u64, _u64, _i64, _vp, _vp, _vp,
-                                 _vp, _vp, _vp],
+                                 _vp, _vp, _vp, _vp, _vp, _vp],
     "mnk_rollout_random": [_vp, _vp, _i64, _i, _i, _i, _i, _u64, _u64, _i64, _vp, _vp, _vp, _vp, _i, _vp],
     "mnk_replay_actions": [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "mnk_unpack_records": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -51,6 +51,7 @@ class TorchSelfPlayWrapper:
         self._forced_sides = None
         self._flags = torch.zeros(self.num_envs, dtype=torch.uint8, device=self._dev)
         self._no_actions = torch.zeros(self.num_envs, dtype=torch.long, device=self._dev)
+        self._ep_return = self._ep_length = self._ep_stats = None  # see track_episodes()
 
     def set_opponent(self, policy):  # reference wrapper:16-17
         self.opponent_policy = policy
@@ -64,6 +65,29 @@ class TorchSelfPlayWrapper:
             t = torch.as_tensor(sides, device=self._dev).to(torch.long)
             self._forced_sides = t.expand(self.num_envs).contiguous() if t.dim() == 0 else t.contiguous()
 
+    # ------------------------------------------------------------------ device-side episode statistics
+    def track_episodes(self, on: bool = True) -> None:
+        """Keep per-env running return / length and finished-episode counters on the device, updated
+        inside the step kernels -- what ``alg/ppo.py:110-120`` computes on the host with two
+        synchronisations per step.  Read (and clear) them with ``pop_episode_stats()``."""
+        if on and self._ep_stats is None:
+            self._ep_return = torch.zeros(self.num_envs, dtype=torch.float32, device=self._dev)
+            self._ep_length = torch.zeros(self.num_envs, dtype=torch.int32, device=self._dev)
+            self._ep_stats = torch.zeros((mnk_hip.STATS_REPLICAS, mnk_hip.STATS_STRIDE), dtype=torch.int64,
+                                         device=self._dev)
+        elif not on:
+            self._ep_return = self._ep_length = self._ep_stats = None
+
+    def pop_episode_stats(self) -> dict:
+        """Episodes finished since the last call (one host synchronisation): counts, mean reward, mean length."""
+        if self._ep_stats is None:
+            raise RuntimeError("call track_episodes() first")
+        episodes, wins, losses, draws, length = self._ep_stats.sum(dim=0)[:mnk_hip.STATS_COUNTERS].tolist()
+        self._ep_stats.zero_()
+        return {"episodes": episodes, "wins": wins, "losses": losses, "draws": draws,
+                "mean_reward": (wins - losses) / episodes if episodes else 0.0,
+                "mean_length": length / episodes if episodes else 0.0}
+
     # ------------------------------------------------------------------ reference surface
     def reset(self, seed=None, options=None):
         """reference wrapper:19-30 (``seed`` is accepted and ignored there; here it re-keys Philox)"""
@@ -76,6 +100,9 @@ class TorchSelfPlayWrapper:
         # a reset is a step in which every env is pending: boards cleared, sides handed out,
         # the opponent opens wherever the agent is white, and its outcome is ignored (:28)
         self.pending_resets.fill_(True)
+        if self._ep_stats is not None:
+            self._ep_return.zero_()
+            self._ep_length.fill_(-1)  # the reset itself is not a step of the first episode
         obs, _, _, _, _ = self._advance(self._no_actions, forced)
         return obs, {}
 
@@ -117,7 +144,8 @@ class TorchSelfPlayWrapper:
                          env.n, env.k, mnk_hip.ptr(actions), mnk_hip.ptr(self.pending_resets),
                          mnk_hip.ptr(self.agent_side), mnk_hip.ptr(forced), self.seed, step, self.env_id0,
                          mnk_hip.ptr(rewards), mnk_hip.ptr(terminated), mnk_hip.ptr(obs), mnk_hip.ptr(mask),
-                         mnk_hip.ptr(env._err), env._stream())
+                         mnk_hip.ptr(env._err), mnk_hip.ptr(self._ep_return), mnk_hip.ptr(self._ep_length),
+                         mnk_hip.ptr(self._ep_stats), env._stream())
         else:
             if opp is None:
                 raise RuntimeError("TorchSelfPlayWrapper: set_opponent(policy) before reset()/step()")
@@ -136,7 +164,8 @@ class TorchSelfPlayWrapper:
             mnk_hip.call("mnk_selfplay_post", mnk_hip.ptr(env._planes), mnk_hip.ptr(env._meta), n, env.m, env.n,
                          env.k, mnk_hip.ptr(opp_actions), mnk_hip.ptr(self._flags), mnk_hip.ptr(self.agent_side),
                          mnk_hip.ptr(rewards), mnk_hip.ptr(terminated), mnk_hip.ptr(self.pending_resets),
-                         mnk_hip.ptr(obs), mnk_hip.ptr(mask), mnk_hip.ptr(env._err), env._stream())
+                         mnk_hip.ptr(obs), mnk_hip.ptr(mask), mnk_hip.ptr(env._err), mnk_hip.ptr(self._ep_return),
+                         mnk_hip.ptr(self._ep_length), mnk_hip.ptr(self._ep_stats), env._stream())
         if env.strict:
             env.check_errors()
         return {"observation": obs, "action_mask": mask}, rewards, terminated, torch.zeros_like(terminated), {}

@@ -425,3 +425,41 @@ def test_full_size_selfplay_properties(hip):
     assert games > 100000
     assert abs(wins - losses) / games < 0.02      # same policy on both sides, sides drawn uniformly
     assert draws / games < 0.01
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_device_episode_stats_equal_the_ppo_host_loop(hip, fused):
+    """track_episodes(): the device-side counters == the bookkeeping of alg/ppo.py:104-120 done on the host
+    (current_ep_reward += rewards; current_ep_len += 1; on done: record and zero)."""
+    m, n, k, nenv = 3, 3, 3, 1000
+    env = hip.Env(m, n, k, nenv, device=DEV)
+    wrap = hip.Wrapper(env, seed=6)
+    opp = hip.policy.RandomPolicy(m * n, seed=1)
+    if not fused:
+        opp.fused_uniform_random = False  # instance attribute: take the pre / policy / post path
+    wrap.set_opponent(opp)
+    wrap.track_episodes()
+    agent = hip.policy.RandomPolicy(m * n, seed=2)
+    obs, _ = wrap.reset()
+    ep_reward = torch.zeros(nenv, device=DEV)
+    ep_len = torch.zeros(nenv, device=DEV)
+    fin_rewards, fin_lengths = [], []
+    for _ in range(60):
+        obs, rew, term, trunc, _ = wrap.step(agent.act(obs))
+        done = term | trunc
+        ep_reward += rew
+        ep_len += 1
+        idx = torch.nonzero(done).squeeze(1)
+        fin_rewards.extend(ep_reward[idx].tolist())
+        fin_lengths.extend(ep_len[idx].tolist())
+        ep_reward[idx] = 0
+        ep_len[idx] = 0
+    stats = wrap.pop_episode_stats()
+    assert stats["episodes"] == len(fin_rewards) > 5000
+    assert stats["wins"] == sum(r == 1.0 for r in fin_rewards)
+    assert stats["losses"] == sum(r == -1.0 for r in fin_rewards)
+    assert stats["draws"] == sum(r == 0.0 for r in fin_rewards)
+    assert abs(stats["mean_length"] - np.mean(fin_lengths)) < 1e-9
+    assert abs(stats["mean_reward"] - np.mean(fin_rewards)) < 1e-9
+    assert wrap.pop_episode_stats()["episodes"] == 0  # popped
+    assert torch.equal(wrap._ep_length.to(torch.float32), ep_len) and torch.equal(wrap._ep_return, ep_reward)
