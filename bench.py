@@ -152,8 +152,8 @@ def replay_rate(env, roll, chunk, reps=8):
 
     rec = roll.alloc(chunk, log_actions=True)
     roll.run(chunk, out=rec)
-    logs = GatheredLogs(planes0=rec.planes[0].unsqueeze(0).clone(), meta0=rec.meta0.unsqueeze(0).clone(),
-                        act=rec.act.unsqueeze(0), steps=chunk)
+    logs = GatheredLogs.empty(1, env.words, env.num_envs, chunk, env.max_moves, env._dev)
+    logs.msg.copy_(rec.msg.unsqueeze(0))
     out = replay_shard(logs, 0, env.m, env.n, env.k)
     assert torch.equal(out.planes, rec.planes) and torch.equal(out.meta, rec.meta), "replay != records"
     torch.cuda.synchronize()
@@ -329,11 +329,7 @@ def main():
             gathered = [(torch.empty((world,) + tuple(b.planes.shape), dtype=torch.int64, device=dev),
                          torch.empty((world,) + tuple(b.meta.shape), dtype=torch.int32, device=dev)) for b in bufs]
         else:
-            gathered = [GatheredLogs(planes0=torch.empty((world, 2, env.words, nenv), dtype=torch.int64, device=dev),
-                                     meta0=torch.empty((world, nenv), dtype=torch.int32, device=dev),
-                                     act=torch.empty((world, (chunk + 3) // 4, nenv),
-                                                     dtype=action_log_dtype(env.max_moves), device=dev),
-                                     steps=chunk) for _ in bufs]
+            gathered = [GatheredLogs.empty(world, env.words, nenv, chunk, env.max_moves, dev) for _ in bufs]
     main_stream = torch.cuda.current_stream(dev)
     gather_done = [None, None]
     kernel_events = []  # (start, end) HIP events around every rollout launch of the timed region
@@ -350,9 +346,7 @@ def main():
             if gather_done[slot] is not None:
                 main_stream.wait_event(gather_done[slot])  # the buffer is free again
             out = bufs[slot]
-            if t != chunk:
-                out = RolloutRecords(planes=out.planes[:t], meta=out.meta[:t],
-                                     act=None if out.act is None else out.act[:(t + 3) // 4], meta0=out.meta0)
+            assert t == chunk  # a bench step is a whole chunk
             if timing[0]:
                 ks, ke = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ks.record(main_stream)
@@ -367,13 +361,9 @@ def main():
                 with torch.cuda.stream(side):
                     side.wait_event(ready)
                     if mode == "actions":
-                        gather_action_logs(out, out=gathered[slot] if t == chunk else None)
+                        gather_action_logs(out, out=gathered[slot])
                     else:
-                        if t == chunk:
-                            gp, gm = gathered[slot]
-                        else:  # ragged last chunk: its own (contiguous) landing buffers
-                            gp = torch.empty((world,) + tuple(out.planes.shape), dtype=torch.int64, device=dev)
-                            gm = torch.empty((world,) + tuple(out.meta.shape), dtype=torch.int32, device=dev)
+                        gp, gm = gathered[slot]
                         dist.all_gather_into_tensor(gp.view(-1), out.planes.view(-1))
                         dist.all_gather_into_tensor(gm.view(-1), out.meta.view(-1))
                     ev = torch.cuda.Event()

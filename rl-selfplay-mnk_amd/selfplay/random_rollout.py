@@ -32,8 +32,11 @@ import mnk_hip
 class RolloutRecords:
     planes: torch.Tensor  # int64 (u64 bits) [T, 2, W, N]
     meta: torch.Tensor    # int32 (u32 bits) [T, N]
-    act: Optional[torch.Tensor] = None    # action log, 4 plies per word: int32 / int64 [ceil(T/4), N] (when logging was on)
-    meta0: Optional[torch.Tensor] = None  # env meta words at the start of the chunk, int32 [N]
+    # only when the action log is on (alloc(..., log_actions=True)); all three are views into `msg`
+    act: Optional[torch.Tensor] = None      # action log, 4 plies per word: int32 / int64 [ceil(T/4), N]
+    meta0: Optional[torch.Tensor] = None    # env meta words at the start of the chunk, int32 [N]
+    planes0: Optional[torch.Tensor] = None  # env planes at the start of the chunk, int64 [2, W, N]
+    msg: Optional[torch.Tensor] = None      # the one flat int64 buffer that is all-gathered
 
     @property
     def steps(self) -> int:
@@ -79,9 +82,9 @@ class RandomRollout:
             meta=torch.empty((steps, env.num_envs), dtype=torch.int32, device=env._dev),
         )
         if log_actions:
-            rec.act = torch.empty(((steps + 3) // 4, env.num_envs), dtype=action_log_dtype(env.max_moves),
+            rec.msg = torch.zeros(_msg_words(env.words, env.num_envs, steps, env.max_moves), dtype=torch.int64,
                                   device=env._dev)
-            rec.meta0 = torch.empty(env.num_envs, dtype=torch.int32, device=env._dev)
+            rec.planes0, rec.act, rec.meta0 = _msg_views(rec.msg, env.words, env.num_envs, steps, env.max_moves)
         return rec
 
     def run(self, steps: int, out: Optional[RolloutRecords] = None, record: bool = True) -> Optional[RolloutRecords]:
@@ -94,8 +97,9 @@ class RandomRollout:
         if record:
             assert out.meta.shape == (steps, env.num_envs) and out.planes.shape[0] == steps
             act = out.act
-            if out.meta0 is not None:
-                out.meta0.copy_(env._meta)  # with planes[0] this is the chunk-start state a replay needs
+            if out.meta0 is not None:  # the chunk-start state a replay needs travels with the log
+                out.meta0.copy_(env._meta)
+                out.planes0.copy_(env._planes)
         if env.num_envs and steps:
             mnk_hip.call("mnk_rollout_random", mnk_hip.ptr(env._planes), mnk_hip.ptr(env._meta), env.num_envs,
                          env.m, env.n, env.k, steps, self.seed, self.step, self.env_id0,
@@ -119,31 +123,65 @@ def unpack_action_log(act: torch.Tensor, steps: int) -> torch.Tensor:
     return torch.stack(fields, dim=1).reshape(-1, act.shape[1])[:steps].to(torch.int64)
 
 
+def _msg_layout(words: int, nenv: int, steps: int, num_actions: int):
+    """Offsets (in int64 words) of the three parts of the exchange message: planes0 | act | meta0."""
+    act_bytes = ((steps + 3) // 4) * nenv * (4 if num_actions <= 256 else 8)
+    n_planes = 2 * words * nenv
+    n_act = (act_bytes + 7) // 8
+    n_meta = (nenv * 4 + 7) // 8
+    return n_planes, n_act, n_meta
+
+
+def _msg_words(words, nenv, steps, num_actions) -> int:
+    return sum(_msg_layout(words, nenv, steps, num_actions))
+
+
+def _msg_views(msg, words, nenv, steps, num_actions):
+    """(planes0 [.., 2, W, N] int64, act [.., ceil(T/4), N] int32/int64, meta0 [.., N] int32) views of a message
+    buffer whose last dimension is the flat message (leading dimensions, e.g. the rank axis, are kept)."""
+    n_planes, n_act, n_meta = _msg_layout(words, nenv, steps, num_actions)
+    lead = msg.shape[:-1]
+    q = (steps + 3) // 4
+    planes0 = msg[..., :n_planes].reshape(lead + (2, words, nenv))
+    act64 = msg[..., n_planes:n_planes + n_act]
+    if num_actions <= 256:
+        act = act64.view(torch.int32)[..., :q * nenv].reshape(lead + (q, nenv))
+    else:
+        act = act64[..., :q * nenv].reshape(lead + (q, nenv))
+    meta0 = msg[..., n_planes + n_act:].view(torch.int32)[..., :nenv]
+    return planes0, act, meta0
+
+
 @dataclass
 class GatheredLogs:
-    """What ``gather_action_logs`` leaves on every rank: per shard r the chunk-start state and the log."""
+    """What ``gather_action_logs`` leaves on every rank: per shard r the chunk-start state and the log,
+    as views of the gathered message buffer ``msg`` [world, L]."""
     planes0: torch.Tensor  # int64 [world, 2, W, N]
     meta0: torch.Tensor    # int32 [world, N]
     act: torch.Tensor      # int32 / int64 [world, ceil(T/4), N]: four plies per word
     steps: int = 0         # T
+    msg: Optional[torch.Tensor] = None
+
+    @staticmethod
+    def empty(world: int, words: int, nenv: int, steps: int, num_actions: int, device) -> "GatheredLogs":
+        msg = torch.empty((world, _msg_words(words, nenv, steps, num_actions)), dtype=torch.int64, device=device)
+        planes0, act, meta0 = _msg_views(msg, words, nenv, steps, num_actions)
+        return GatheredLogs(planes0=planes0, meta0=meta0, act=act, steps=steps, msg=msg)
 
 
 def gather_action_logs(rec: RolloutRecords, group=None, out: Optional[GatheredLogs] = None) -> GatheredLogs:
-    """All-gather of (chunk-start state, action log): 1-2 bytes per env-step on the wire."""
+    """All-gather of (chunk-start state, action log) as ONE message per rank: 1-2 bytes per env-step on the
+    wire plus the 36 B/env state once per chunk."""
     import torch.distributed as dist
 
-    assert rec.act is not None and rec.meta0 is not None, "run the rollout with alloc(..., log_actions=True)"
+    assert rec.msg is not None, "run the rollout with alloc(..., log_actions=True)"
     world = dist.get_world_size(group)
     t, two, w, n = rec.planes.shape
-    dev = rec.planes.device
+    num_actions = 256 if rec.act.dtype == torch.int32 else 65536
     if out is None:
-        out = GatheredLogs(planes0=torch.empty((world, two, w, n), dtype=torch.int64, device=dev),
-                           meta0=torch.empty((world, n), dtype=torch.int32, device=dev),
-                           act=torch.empty((world,) + tuple(rec.act.shape), dtype=rec.act.dtype, device=dev))
-    out.steps = t
-    dist.all_gather_into_tensor(out.planes0.view(-1), rec.planes[0].reshape(-1), group=group)
-    dist.all_gather_into_tensor(out.meta0.view(-1), rec.meta0.view(-1), group=group)
-    dist.all_gather_into_tensor(out.act.view(-1), rec.act.view(-1), group=group)
+        out = GatheredLogs.empty(world, w, n, t, num_actions, rec.msg.device)
+    assert out.msg.shape == (world, rec.msg.numel()) and out.steps == t
+    dist.all_gather_into_tensor(out.msg.view(-1), rec.msg, group=group)
     return out
 
 

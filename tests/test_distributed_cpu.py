@@ -45,8 +45,13 @@ def _worker(rank, world, port, m, n, k, nenv, steps, seed, out_dir):
         acts = (meta & 0xFFFF).astype(np.int64)
         pad = np.zeros(((-steps) % 4, nenv), dtype=np.int64)
         quads = np.concatenate([acts, pad]).reshape(-1, 4, nenv)
-        rec.act = torch.from_numpy((quads[:, 0] | quads[:, 1] << 8 | quads[:, 2] << 16 | quads[:, 3] << 24).astype(np.int32))
-        rec.meta0 = torch.zeros(nenv, dtype=torch.int32)  # every env starts from reset
+        from selfplay.random_rollout import _msg_views, _msg_words
+        words = planes.shape[2]
+        rec.msg = torch.zeros(_msg_words(words, nenv, steps, m * n), dtype=torch.int64)
+        rec.planes0, rec.act, rec.meta0 = _msg_views(rec.msg, words, nenv, steps, m * n)
+        rec.act.copy_(torch.from_numpy((quads[:, 0] | quads[:, 1] << 8 | quads[:, 2] << 16 | quads[:, 3] << 24).astype(np.int32)))
+        rec.planes0.copy_(rec.planes[0])
+        rec.meta0.zero_()  # every env starts from reset
         logs = gather_action_logs(rec)
         assert logs.act.shape == (world, (steps + 3) // 4, nenv) and logs.planes0.shape[0] == world and logs.steps == steps
         assert torch.equal(logs.act[rank], rec.act) and torch.equal(logs.planes0[rank], rec.planes[0])

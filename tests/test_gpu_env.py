@@ -244,8 +244,9 @@ def test_action_log_replay_rebuilds_the_records(hip, m, n, k, nenv, steps):
         assert rec.act.shape == ((steps + 3) // 4, nenv)
         actions = unpack_action_log(rec.act, steps)
         assert torch.equal(actions, rec.actions())
-        logs = GatheredLogs(planes0=rec.planes[0].unsqueeze(0).clone(), meta0=rec.meta0.unsqueeze(0).clone(),
-                            act=rec.act.unsqueeze(0).clone(), steps=steps)
+        assert torch.equal(rec.planes0, rec.planes[0])  # the chunk-start state travels with the log
+        logs = GatheredLogs.empty(1, env.words, nenv, steps, m * n, DEV)
+        logs.msg.copy_(rec.msg.unsqueeze(0))  # what a one-rank all-gather delivers
         again = replay_shard(logs, 0, m, n, k)
         assert torch.equal(again.planes, rec.planes) and torch.equal(again.meta, rec.meta)
         planes, meta = oracle_replay(ora, actions.cpu().numpy())
