@@ -1,11 +1,9 @@
-"""Constants of the MNK env -- same names and values as the reference's
-``src/env/constants.py:1-9`` so callers can import them unchanged."""
-PLAYER_BLACK = 0
-PLAYER_WHITE = 1
+"""Player / channel / reward constants of the MNK env.
 
-CHANNEL_ME = 0
-CHANNEL_ENEMY = 1
-
-REWARD_WIN = 1.0
-REWARD_LOSS = -1.0
-REWARD_DRAW = 0.0
+Same names and values as the reference module (``src/env/constants.py:1-9``), because callers
+import them by name; the HIP kernels hard-wire the same encoding (side bit 0 = black, channel 0 =
+the viewer's own stones, rewards exactly +1.0 / -1.0 / 0.0).
+"""
+PLAYER_BLACK, PLAYER_WHITE = 0, 1          # bit 0 of the packed meta word
+CHANNEL_ME, CHANNEL_ENEMY = 0, 1           # observation planes as the viewer sees them
+REWARD_WIN, REWARD_LOSS, REWARD_DRAW = 1.0, -1.0, 0.0
