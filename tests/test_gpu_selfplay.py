@@ -463,3 +463,53 @@ def test_device_episode_stats_equal_the_ppo_host_loop(hip, fused):
     assert abs(stats["mean_reward"] - np.mean(fin_rewards)) < 1e-9
     assert wrap.pop_episode_stats()["episodes"] == 0  # popped
     assert torch.equal(wrap._ep_length.to(torch.float32), ep_len) and torch.equal(wrap._ep_return, ep_reward)
+
+
+@pytest.mark.parametrize("m,n,k,p1_is_black", [(3, 3, 3, True), (3, 3, 3, False), (9, 9, 5, True), (4, 6, 3, False)])
+def test_tournament_loop_equals_reference_bookkeeping(hip, m, n, k, p1_is_black):
+    """selfplay/tournament.py (lockstep, one sync) against the reference's MatchRunner._play_batch_games
+    algorithm (match_runner.py:149-215: active subsets, step_subset, first-finish counting) run on the oracle
+    env with the very actions the HIP run drew."""
+    from selfplay.tournament import play_batch_games
+
+    games = 700
+    log = []
+
+    class Logged:
+        def __init__(self, inner):
+            self.inner = inner
+
+        def act(self, obs, deterministic=False):
+            a = self.inner.act(obs, deterministic)
+            log.append((obs["observation"].cpu(), obs["action_mask"].cpu(), a.cpu()))
+            return a
+
+    p1, p2 = Logged(hip.policy.RandomPolicy(m * n, seed=1)), Logged(hip.policy.RandomPolicy(m * n, seed=2))
+    got = play_batch_games(p1, p2, (m, n, k), games, p1_is_black, device=DEV)
+
+    ora = OracleVectorEnv(m, n, k, games)
+    obs = ora.reset()
+    over = torch.zeros(games, dtype=torch.bool)
+    agent_side = 0 if p1_is_black else 1
+    wins = losses = draws = 0
+    for ply, (seen_obs, seen_mask, acts) in enumerate(log):
+        if bool(over.all()):
+            break
+        active = ~over
+        is_p1 = (ora.current_player == agent_side) & active
+        # what the running games' mover saw on the GPU is what the reference would have shown it
+        view = obs["observation"].clone()
+        white = ora.current_player == 1
+        view[white] = view[white].flip(1)
+        assert torch.equal(seen_obs[active], view[active]) and torch.equal(seen_mask[active], obs["action_mask"][active])
+        idx = torch.nonzero(active).squeeze(1)
+        obs, rew, done = ora.step_subset(acts[idx], idx)
+        fresh = done & ~over
+        won = (rew == 1.0) & fresh
+        wins += int((won & is_p1).sum())
+        losses += int((won & ~is_p1).sum())
+        draws += int(((rew == 0.0) & fresh).sum())
+        over |= fresh
+    assert bool(over.all())
+    assert got == (wins, losses, draws)
+    assert sum(got) == games
