@@ -198,6 +198,13 @@ int mnk_unpack_records(const uint64_t* rec_planes, const uint32_t* rec_meta, int
                        float* obs, uint8_t* masks, int64_t* actions, float* rewards, uint8_t* dones,
                        void* stream);
 
+/* ---- alg/rollout_buffer.py:82-113 get_data_loader: a shuffled minibatch straight from PACKED observations.
+ * planes u64[T][2][W][N] (channel 0 = the viewer's stones, as the wrapper hands them out); idx int64[B] flat
+ * sample ids t*N + i (negative ids wrap, out-of-range -> err).  Writes the network inputs of the B samples:
+ * obs f32[B][2][m][n] and legal mask u8[B][m*n] (free cells; fix_empty_mask as in wrapper:108-110). */
+int mnk_gather_obs(const uint64_t* planes, int64_t T, int64_t N, int m, int n, const int64_t* idx, int64_t B,
+                   float* obs, uint8_t* legal_mask, int fix_empty_mask, int32_t* err, void* stream);
+
 /* ---- alg/rollout_buffer.py:60-80 compute_advantages_and_returns (GAE), one lane per env ---- */
 int mnk_gae(const float* rewards, const float* values, const uint8_t* dones, const float* last_values,
             int64_t N, int T, float gamma, float gamma_lambda, float* advantages, float* returns,

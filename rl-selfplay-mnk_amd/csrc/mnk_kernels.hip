@@ -473,6 +473,45 @@ k_unpack_records(MnkGeom g, const uint64_t* rec_planes, const uint32_t* rec_meta
   }
 }
 
+// ------------------------------------------------------------------ minibatch gather from packed observations
+// alg/rollout_buffer.py:82-113 (get_data_loader) indexes f32 [T*N, 2, m, n] observations and bool masks with a
+// random permutation -- 729 B read + 729 B written per sample at 9x9.  Here the buffer keeps the packed planes
+// (32 B per sample) and this kernel expands the drawn samples straight into the network's input layout:
+// sample j = flat id idx[j] = t*N + i; lane j fetches its planes (a 32-byte random gather), the workgroup
+// writes its contiguous slab of observations and masks through the LDS stage.
+template <int NW, int CN, int CK>
+__global__ void __launch_bounds__(256)
+k_gather_obs(MnkGeom g, const uint64_t* planes, int64_t T, int64_t N, const int64_t* idx, int64_t B_total, float* obs,
+             uint8_t* legal_mask, int fix_empty, int32_t* err, int vec_ok, int envs_per_block) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * B;
+  const int64_t j = row0 + tid;
+  MnkStage st = mnk_stage_carve(lds_raw, g, B);
+  mnk_stage_tables(st, g, B, tid, NT);
+  if (tid < B && j < B_total) {
+    int64_t flat = idx[j];
+    if (flat < 0) flat += T * N;
+    uint32_t p0[NW], p1[NW];
+    if (flat < 0 || flat >= T * N) {
+      mnk_report(err, MNK_ERR_ACTION_RANGE, idx[j]);
+#pragma unroll
+      for (int w = 0; w < NW; ++w) p0[w] = p1[w] = 0u;
+    } else {
+      const int64_t t = flat / N, i = flat - t * N;
+      const uint64_t* base = planes + t * 2 * g.W * N;
+      plane_load<NW>(p0, base, N, g.W, i);
+      plane_load<NW>(p1, base + (int64_t)g.W * N, N, g.W, i);
+    }
+    mnk_stage_put<NW>(st, g, B, tid, p0, p1, fix_empty != 0);
+  }
+  __syncthreads();
+  const int64_t left = B_total - row0;
+  const int nb = left < B ? (int)left : B;
+  if (obs) mnk_emit_obs(st, g, nb, obs + row0 * 2 * g.C, vec_ok & 1, tid, NT);
+  if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + row0 * g.C, (vec_ok >> 1) & 1, tid, NT);
+}
+
 // ------------------------------------------------------------------ GAE (alg/rollout_buffer.py:60-80)
 // one lane per env, reverse scan over T; every access is coalesced over the env axis.  The
 // operation order and the f32 roundings are the reference's (built with -ffp-contract=off).
@@ -745,6 +784,22 @@ int mnk_unpack_records(const uint64_t* rec_planes, const uint32_t* rec_meta, int
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_unpack_records), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, rec_planes,
                                          rec_meta, N, obs, masks, actions, rewards, dones, vec_ok, B));
   return mnk_launch_status("unpack_records");
+}
+
+int mnk_gather_obs(const uint64_t* planes, int64_t T, int64_t N, int m, int n, const int64_t* idx, int64_t B,
+                   float* obs, uint8_t* legal_mask, int fix_empty_mask, int32_t* err, void* stream) {
+  MnkGeom g;
+  int rc = mnk_geom_any_k(m, n, &g);
+  if (rc != MNK_OK) return rc;
+  if (!planes || T < 0 || N < 0 || B < 0 || (B > 0 && !idx)) return MNK_EINVAL;
+  if (B == 0 || (!obs && !legal_mask)) return MNK_OK;
+  const int E = mnk_block_envs(B);
+  const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
+  const size_t lds = mnk_stage_bytes(g.NW, g.C, E);
+  const dim3 grid((unsigned)((B + E - 1) / E));
+  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_gather_obs), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g,
+                                     planes, T, N, idx, B, obs, legal_mask, fix_empty_mask, err, vec_ok, E));
+  return mnk_launch_status("gather_obs");
 }
 
 int mnk_gae(const float* rewards, const float* values, const uint8_t* dones, const float* last_values, int64_t N,

@@ -49,6 +49,7 @@ SIGNATURES = {
     "mnk_rollout_random": [_vp, _vp, _i64, _i, _i, _i, _i, _u64, _u64, _i64, _vp, _vp, _vp, _vp, _i, _vp],
     "mnk_replay_actions": [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "mnk_unpack_records": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mnk_gather_obs": [_vp, _i64, _i64, _i, _i, _vp, _i64, _vp, _vp, _i, _vp, _vp],
     "mnk_gae": [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp],
 }
 

@@ -123,6 +123,13 @@ class TorchSelfPlayWrapper:
 
     _get_canonical_obs = get_agent_obs
 
+    def packed_obs(self) -> torch.Tensor:
+        """The current canonical observation as packed planes, int64 [2, W, N] (channel 0 = the agent's
+        stones): 32 B per env at 9x9 instead of the 729 B of observation + mask.  Feed it to
+        ``alg.packed_rollout_buffer.PackedRolloutBuffer.add``; take it before the next ``step``."""
+        planes = self.env._planes
+        return torch.where((self.agent_side == 1).view(1, 1, -1), planes.flip(0), planes)
+
     # ------------------------------------------------------------------ one fused step
     def _advance(self, actions, forced):
         env = self.env

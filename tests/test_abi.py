@@ -35,7 +35,7 @@ def test_header_declares_the_path():
     decl = declared_functions()
     for name in ("mnk_step", "mnk_observe", "mnk_reset_all", "mnk_reset_idx", "mnk_sample_legal",
                  "mnk_rollout_random", "mnk_replay_actions", "mnk_selfplay_pre", "mnk_selfplay_post", "mnk_sample_logits",
-                 "mnk_pack_boards", "mnk_unpack_boards", "mnk_unpack_records", "mnk_gae"):
+                 "mnk_pack_boards", "mnk_unpack_boards", "mnk_unpack_records", "mnk_gather_obs", "mnk_gae"):
         assert name in decl
 
 

@@ -513,3 +513,49 @@ def test_tournament_loop_equals_reference_bookkeeping(hip, m, n, k, p1_is_black)
     assert bool(over.all())
     assert got == (wins, losses, draws)
     assert sum(got) == games
+
+
+@pytest.mark.parametrize("m,n,k", [(3, 3, 3), (9, 9, 5), (19, 19, 5)])
+def test_packed_rollout_buffer_equals_the_dense_one(hip, m, n, k):
+    """alg/packed_rollout_buffer.py: packed planes in, and the minibatch gather (mnk_gather_obs) hands back
+    exactly the observations and masks the dense drop-in buffer stored; GAE identical."""
+    from alg.packed_rollout_buffer import PackedRolloutBuffer
+    from alg.rollout_buffer import RolloutBuffer
+
+    nenv, steps, c = 300, 12, m * n
+    env = hip.Env(m, n, k, nenv, device=DEV)
+    wrap = hip.Wrapper(env, seed=9)
+    wrap.set_opponent(hip.policy.RandomPolicy(c, seed=1))
+    agent = hip.policy.RandomPolicy(c, seed=2)
+    dense = RolloutBuffer(steps, nenv, (2, m, n), c, device=DEV)
+    packed = PackedRolloutBuffer(steps, nenv, m, n, device=DEV)
+    obs, _ = wrap.reset()
+    for _ in range(steps - 2):  # a partly filled buffer
+        pobs = wrap.packed_obs()
+        acts = agent.act(obs)
+        nobs, rew, term, trunc, _ = wrap.step(acts)
+        val = torch.randn(nenv, 1, device=DEV)
+        lp = torch.randn(nenv, device=DEV)
+        dense.add(obs["observation"], acts, rew, val, lp, term | trunc, obs["action_mask"])
+        packed.add(pobs, acts, rew, val, lp, term | trunc)
+        obs = nobs
+    last = torch.randn(nenv, device=DEV)
+    dense.compute_advantages_and_returns(last)
+    packed.compute_advantages_and_returns(last)
+    assert torch.equal(dense.advantages, packed.advantages) and torch.equal(dense.returns, packed.returns)
+    filled = (steps - 2) * nenv
+    idx = torch.randperm(filled, device=DEV)[:1000]
+    o, msk = packed.gather(idx)
+    assert torch.equal(o, dense.observations.reshape(-1, 2, m, n)[idx])
+    assert torch.equal(msk, dense.action_masks.reshape(-1, c)[idx])
+    o, msk = packed.gather(torch.tensor([-1, 0, filled - 1], device=DEV))   # negative ids wrap
+    assert torch.equal(o[1], dense.observations[0, 0]) and torch.equal(o[2], dense.observations[steps - 3, nenv - 1])
+    seen = 0
+    for b in packed.get_data_loader(777):
+        assert b[0].shape[1:] == (2, m, n) and b[5].shape[1] == c and b[0].shape[0] == b[1].shape[0] == b[5].shape[0]
+        assert bool(torch.gather(b[5], 1, b[1].unsqueeze(1)).all())  # the stored action was legal under the rebuilt mask
+        seen += b[0].shape[0]
+    assert seen == filled
+    with pytest.raises(IndexError, match="Buffer was full."):
+        for _ in range(3):
+            packed.add(pobs, acts, rew, val, lp, term)
