@@ -355,7 +355,6 @@ k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, c
 // ------------------------------------------------------------------ masked categorical head + draw
 // alg/architectures/cnn.py:69-79 fused with Categorical.sample (policy.py:46-52).  One wave per
 // row: lanes stride over the C cells, a butterfly (shuffle-xor) argmax picks the winner of the
-// Gumbel-perturbed masked logits; ties go to the lowest cell like torch.argmax.
 // reductions over one 32-lane half of the wave (a row of logits lives in one half)
 __device__ __forceinline__ void half_argmax(float& v, int& idx) {
 #pragma unroll
@@ -378,9 +377,17 @@ __device__ __forceinline__ float half_sum(float v) {
   return v;
 }
 
-// Two rows per wave (one per 32-lane half); a lane takes 4 consecutive cells per sweep, so one
-// Philox block feeds its four Gumbel draws.  -log(-log u) uses the hardware log (v_log_f32): the
-// draw only has to be distributed right (chi-square test), the reported log-prob uses accurate logf.
+// Two rows per wave (one per 32-lane half).  The draw is an inverse-CDF lookup, not a per-cell perturbation:
+// lane l of the half owns the K = ceil(C/32) consecutive cells [l*K, (l+1)*K), weights e^(logit - max) are
+// summed per lane, a 5-step shuffle scan gives every lane the weight in front of it, ONE Philox uniform per row
+// picks the point u * total on that axis, a ballot finds the lane that holds it and that lane walks its K
+// cells.  One exp per cell instead of one Philox block + two logs per four cells (Gumbel-max, measured first:
+// 44 us for 65 536 x 81).  Distribution = softmax over the legal cells (chi-square test); ties / rounding at the
+// very end of the axis fall on the last legal cell.
+// K = cells per lane is a template parameter (loops fully unrolled, all loads of a lane issued together
+// with clamped addresses: per-cell predicated loads serialised into ~16 memory round trips).
+#define SAMPLE_MAX_K 16  // boards up to 512 cells
+template <int K>
 __global__ void __launch_bounds__(64)
 k_sample_logits(const float* logits, const uint8_t* mask, int64_t N, int C, uint64_t seed, uint64_t step,
                 int64_t env_id0, int deterministic, int64_t* actions, float* logp) {
@@ -391,48 +398,79 @@ k_sample_logits(const float* logits, const uint8_t* mask, int64_t N, int C, uint
   const float* lrow = logits + i * C;
   const uint8_t* mrow = mask + i * C;
   const float NEG = -__builtin_huge_valf();
-  // does the row have a legal cell at all?  (cnn.py:76-77: all-masked -> zeros -> uniform)
+  const int c_lo = sub * K;
+  // this lane's cells: logit and legality (addresses clamped into the row, validity applied afterwards)
+  float raw[K];
+  uint8_t ok[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const int c = min(c_lo + j, C - 1);
+    raw[j] = lrow[c];
+    ok[j] = mrow[c];
+  }
+  float l[K];
   int any = 0;
-  for (int c = sub; c < C; c += 32) any |= mrow[c];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const bool legal = (c_lo + j < C) && ok[j] != 0;
+    any |= legal ? 1 : 0;
+    l[j] = legal ? raw[j] : NEG;
+  }
+  // does the row have a legal cell at all?  (cnn.py:76-77: all-masked -> zeros -> uniform over all cells)
   const unsigned long long votes = __ballot(any != 0);
   const bool none_legal = ((uint32_t)(votes >> (32 * half))) == 0u;
-  const uint64_t env = (uint64_t)(env_id0 + i);
-  const uint32_t CB = (uint32_t)((C + 3) >> 2);
-  float best = NEG, vmax = NEG;
-  int besti = 0x7fffffff;
-  for (int c0 = sub * 4; c0 < C; c0 += 128) {
-    Philox4 blk;
-    if (!deterministic) blk = mnk_rng_block(seed, env, step * (uint64_t)CB + (uint64_t)(c0 >> 2), MNK_STREAM_GUMBEL);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = c0 + j;
-      if (c < C) {
-        const bool legal = none_legal || mrow[c] != 0;
-        const float l = none_legal ? 0.0f : lrow[c];
-        if (legal) {
-          vmax = fmaxf(vmax, l);
-          float score = l;
-          if (!deterministic) {
-            const float u = ((float)(blk.v[j] >> 8) + 0.5f) * 5.9604644775390625e-08f;  // (0,1)
-            score = l - __logf(-__logf(u));
-          }
-          if (score > best || (score == best && c < besti)) { best = score; besti = c; }
-        }
-      }
-    }
+  for (int j = 0; j < K; ++j) l[j] = none_legal ? ((c_lo + j < C) ? 0.0f : NEG) : l[j];
+  float vmax = NEG;
+  int amax = 0x7fffffff;
+#pragma unroll
+  for (int j = 0; j < K; ++j)
+    if (l[j] > vmax) { vmax = l[j]; amax = c_lo + j; }  // first maximum of the lane, cells ascend
+  float rowmax = vmax;
+  int rowarg = amax;
+  half_argmax(rowmax, rowarg);  // ties -> lowest cell, like torch.argmax (policy.py:48-49)
+  float w[K];
+  float mine = 0.0f;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    w[j] = (l[j] == NEG) ? 0.0f : __expf(l[j] - rowmax);
+    mine += w[j];
   }
-  half_argmax(best, besti);
-  if (logp) {
-    vmax = half_max(vmax);
-    float se = 0.0f;
-    for (int c = sub; c < C; c += 32) {
-      const bool legal = none_legal || mrow[c] != 0;
-      if (legal) se += expf((none_legal ? 0.0f : lrow[c]) - vmax);
-    }
-    se = half_sum(se);
-    if (sub == 0 && live) logp[row] = (none_legal ? 0.0f : lrow[besti]) - vmax - logf(se);
+  // inclusive scan over the 32 lanes of the half
+  float incl = mine;
+#pragma unroll
+  for (int off = 1; off < 32; off <<= 1) {
+    const float up = __shfl_up(incl, off, 32);
+    if (sub >= off) incl += up;
   }
-  if (sub == 0 && live) actions[row] = besti;
+  const float total = __shfl(incl, 31, 32);
+  int chosen = rowarg;
+  if (!deterministic) {
+    const uint32_t x = mnk_rand_u32(seed, (uint64_t)(env_id0 + i), step, MNK_STREAM_GUMBEL);
+    const float u = ((float)(x >> 8) + 0.5f) * 5.9604644775390625e-08f;  // (0,1)
+    const float target = u * total;
+    // first lane whose inclusive sum passes the target (the last lane with weight, if rounding overshoots)
+    const unsigned long long pass = __ballot(incl > target && mine > 0.0f);
+    const unsigned long long heavy = __ballot(mine > 0.0f);
+    const uint32_t pass_h = (uint32_t)(pass >> (32 * half)), heavy_h = (uint32_t)(heavy >> (32 * half));
+    const int owner = pass_h ? __ffs(pass_h) - 1 : 31 - __clz(heavy_h);
+    // every lane walks its own cells (no divergence); the owner's answer is broadcast
+    float run = incl - mine;
+    int pick = 0x7fffffff, last = c_lo;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      run += w[j];
+      const bool has = w[j] > 0.0f;
+      last = has ? c_lo + j : last;
+      pick = (has && pick == 0x7fffffff && run > target) ? c_lo + j : pick;
+    }
+    pick = pick == 0x7fffffff ? last : pick;
+    chosen = __shfl(pick, owner, 32);
+  }
+  if (sub == 0 && live) {
+    actions[row] = chosen;
+    if (logp) logp[row] = (none_legal ? 0.0f : lrow[chosen]) - rowmax - logf(total);
+  }
 }
 
 // ------------------------------------------------------------------ records -> RolloutBuffer layout
@@ -758,11 +796,24 @@ int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m,
 
 int mnk_sample_logits(const float* logits, const uint8_t* mask, int64_t N, int C, uint64_t seed, uint64_t step,
                       int64_t env_id0, int deterministic, int64_t* actions, float* logp, void* stream) {
-  if (!logits || !mask || !actions || N < 0 || C < 1 || C > 65535) return MNK_EINVAL;
+  if (!logits || !mask || !actions || N < 0 || C < 1 || C > 32 * SAMPLE_MAX_K) return MNK_EINVAL;
   if (N == 0) return MNK_OK;
   if (N > 0x7fffffffLL) return MNK_EINVAL;
-  hipLaunchKernelGGL(k_sample_logits, dim3((unsigned)((N + 1) / 2)), dim3(64), 0, (hipStream_t)stream, logits, mask, N,
-                     C, seed, step, env_id0, deterministic, actions, logp);
+  const dim3 grid((unsigned)((N + 1) / 2));
+#define MNK_SAMPLE(KV)                                                                                             \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_logits<KV>), grid, dim3(64), 0, (hipStream_t)stream, logits, mask, N, \
+                     C, seed, step, env_id0, deterministic, actions, logp)
+  switch ((C + 31) / 32) {  // cells per lane
+    case 1: MNK_SAMPLE(1); break;
+    case 2: MNK_SAMPLE(2); break;
+    case 3: MNK_SAMPLE(3); break;   // 9x9
+    case 4: MNK_SAMPLE(4); break;
+    case 5: case 6: MNK_SAMPLE(6); break;   // 13x13
+    case 7: case 8: MNK_SAMPLE(8); break;   // 15x15
+    case 9: case 10: case 11: case 12: MNK_SAMPLE(12); break;   // 19x19
+    default: MNK_SAMPLE(16); break;
+  }
+#undef MNK_SAMPLE
   return mnk_launch_status("sample_logits");
 }
 

@@ -1,7 +1,7 @@
 """Policies with the reference's ``act(obs, deterministic=False) -> (B,) int64`` contract
 (``/root/reference/src/selfplay/policy.py:7-54``), drawing through the HIP sampler.
 
-``RandomPolicy``   uniform over the legal cells (policy.py:13-29) -- Gumbel-max over a zero
+``RandomPolicy``   uniform over the legal cells (policy.py:13-29) -- the masked draw over a zero
                    logit row in ``mnk_sample_logits``; as a wrapper opponent it is recognised
                    (``fused_uniform_random``) and the whole self-play step becomes one launch.
 ``NNPolicy``       the reference's network policy, unchanged in behaviour: the net applies
