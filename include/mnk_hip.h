@@ -76,7 +76,7 @@ extern "C" {
 #define MNK_STREAM_MOVE 0
 #define MNK_STREAM_OPP 1
 #define MNK_STREAM_SIDE 2
-#define MNK_STREAM_GUMBEL 3
+#define MNK_STREAM_SAMPLE 3
 
 int mnk_abi_version(void);
 /* W = ceil(m*(n+1)/64), or 0 when the geometry is unsupported */
@@ -127,7 +127,7 @@ int mnk_sample_legal(const uint64_t* planes, int64_t N, int m, int n, uint64_t s
 /* ---- alg/architectures/cnn.py:69-79 (= resnet.py:84-95, transformer.py:80-91) + policy.py:46-52
  * Masked categorical head fused with the draw: logits f32[N][C] (any additive normalisation),
  * mask u8[N][C], C <= 512.  deterministic != 0 -> argmax over legal cells (policy.py:48-49); else an
- * inverse-CDF draw from softmax(masked logits) with one Philox uniform per row (stream MNK_STREAM_GUMBEL).
+ * inverse-CDF draw from softmax(masked logits) with one Philox uniform per row (stream MNK_STREAM_SAMPLE).
  * All-masked row -> uniform over C (cnn.py:76-77).
  * logp (optional) = log-probability of the chosen action under the masked softmax. */
 int mnk_sample_logits(const float* logits, const uint8_t* mask, int64_t N, int C, uint64_t seed,

@@ -15,15 +15,14 @@ known-answer statistics in BASELINE.md §2.
 Counter layout (must match ``csrc/mnk_rng.h``):
     key = (seed_lo32, seed_hi32)
     ctr = (env_lo32, env_hi32, q_lo32, stream | (q_hi24 << 8))
-    scalar streams: q = step >> 2, output word = step & 3
-    STREAM_GUMBEL : q = step * ceil(C/4) + (cell >> 2), output word = cell & 3
+    every stream: q = step >> 2, output word = step & 3
 """
 import numpy as np
 
 STREAM_MOVE = 0    # mover's action in the raw rollout / the agent's action
 STREAM_OPP = 1     # opponent's action in the fused self-play step
 STREAM_SIDE = 2    # side draw at (auto)reset: top bit of the word
-STREAM_GUMBEL = 3  # per-cell uniforms of the masked-logits sampler
+STREAM_SAMPLE = 3  # the one uniform per row of the masked-logits sampler (inverse-CDF draw)
 
 _M0 = np.uint64(0xD2511F53)
 _M1 = np.uint64(0xCD9E8D57)
@@ -65,17 +64,6 @@ def rand_u32(seed: int, env_ids, step, stream: int) -> np.ndarray:
     step = np.asarray(step, dtype=np.uint64)
     blk = _block(seed, env_ids, step >> np.uint64(2), stream)
     word = np.broadcast_to(step & np.uint64(3), blk[0].shape)
-    return np.choose(word.astype(np.int64), blk)
-
-
-def rand_u32_cells(seed: int, env_ids, step: int, ncell: int) -> np.ndarray:
-    """(N, ncell) u32 for STREAM_GUMBEL."""
-    env_ids = np.asarray(env_ids, dtype=np.uint64).reshape(-1, 1)
-    cb = (ncell + 3) // 4
-    cell = np.arange(ncell, dtype=np.uint64).reshape(1, -1)
-    q = np.uint64(step) * np.uint64(cb) + (cell >> np.uint64(2))
-    blk = _block(seed, env_ids, q, STREAM_GUMBEL)
-    word = np.broadcast_to(cell & np.uint64(3), blk[0].shape)
     return np.choose(word.astype(np.int64), blk)
 
 

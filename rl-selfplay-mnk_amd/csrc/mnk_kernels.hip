@@ -446,7 +446,7 @@ k_sample_logits(const float* logits, const uint8_t* mask, int64_t N, int C, uint
   const float total = __shfl(incl, 31, 32);
   int chosen = rowarg;
   if (!deterministic) {
-    const uint32_t x = mnk_rand_u32(seed, (uint64_t)(env_id0 + i), step, MNK_STREAM_GUMBEL);
+    const uint32_t x = mnk_rand_u32(seed, (uint64_t)(env_id0 + i), step, MNK_STREAM_SAMPLE);
     const float u = ((float)(x >> 8) + 0.5f) * 5.9604644775390625e-08f;  // (0,1)
     const float target = u * total;
     // first lane whose inclusive sum passes the target (the last lane with weight, if rounding overshoots)

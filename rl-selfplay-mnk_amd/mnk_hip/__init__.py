@@ -17,7 +17,7 @@ MNK_OK = 0
 ERR_NONE, ERR_ACTION_RANGE, ERR_ILLEGAL_MOVE = 0, 1, 2
 STEP_STRICT = 1
 SP_NEED_OPP, SP_WAS_RESET = 1, 2
-STREAM_MOVE, STREAM_OPP, STREAM_SIDE, STREAM_GUMBEL = 0, 1, 2, 3
+STREAM_MOVE, STREAM_OPP, STREAM_SIDE, STREAM_SAMPLE = 0, 1, 2, 3
 STATS_REPLICAS, STATS_STRIDE, STATS_COUNTERS = 64, 8, 5
 REC_ACTION_MASK, REC_REWARD_SHIFT, REC_DONE_BIT, REC_SIDE_BIT = 0xFFFF, 16, 24, 25
 
