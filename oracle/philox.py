@@ -12,7 +12,7 @@ selection rules in numpy so the kernels can be checked bit for bit; the
 distribution itself (uniform over legal cells = ``RandomPolicy``) is pinned by the
 known-answer statistics in BASELINE.md §2.
 
-Counter layout (must match ``csrc/mnk_rng.h``):
+Counter layout (must match ``mnk_rng_block`` in ``csrc/mnk_device.h``):
     key = (seed_lo32, seed_hi32)
     ctr = (env_lo32, env_hi32, q_lo32, stream | (q_hi24 << 8))
     every stream: q = step >> 2, output word = step & 3
