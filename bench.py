@@ -397,6 +397,20 @@ def main():
 
     plies = args.steps * chunk
     value = world * nenv * plies / dt
+    # SURVEY.md section 8d asks for repetitions: four more timed regions of the same K steps (not part of `value`)
+    reps = [value]
+    timing[0] = False
+    for _ in range(4):
+        barrier()
+        r0 = time.perf_counter()
+        run_steps(args.steps * chunk)
+        barrier()
+        rdt = time.perf_counter() - r0
+        if world > 1:
+            rmax = torch.tensor([rdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
+            rdt = float(rmax.item())
+        reps.append(world * nenv * plies / rdt)
     words = env.words
     # roofline of the dominant kernel (mnk_rollout_random): algorithmic bytes per launch / avg launch time
     plies_per_launch = chunk
@@ -412,6 +426,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt * 1e3 / args.steps,
+        "repetitions": {"values": reps, "median": sorted(reps)[len(reps) // 2], "min": min(reps), "max": max(reps)},
         "step_definition": f"one launch of the fused rollout kernel = {chunk} plies on each of {nenv} envs per GPU",
         "higher_is_better": True,
         "scaling": "weak",
