@@ -173,6 +173,10 @@ class TorchVectorMnkEnv:
                              "(2 <= n <= 61, m*(n+1) <= 512 bits)")
         if dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
+        elif dev.index != torch.cuda.current_device():
+            # kernels are launched on torch's current stream of this device; HIP wants that device current
+            raise ValueError(f"TorchVectorMnkEnv(device={device!r}): make it the current device first "
+                             f"(torch.cuda.set_device({dev.index})); one process per GPU is the intended layout")
         self.m, self.n, self.k = int(m), int(n), int(k)
         self.num_envs = int(num_envs)
         self.device = device

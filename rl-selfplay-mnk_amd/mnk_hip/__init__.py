@@ -97,9 +97,15 @@ def stream_ptr(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+_bound = {}
+
+
 def call(name, *args):
-    lib = load()
-    rc = getattr(lib, name)(*args)
+    fn = _bound.get(name)
+    if fn is None:
+        fn = _bound[name] = getattr(load(), name)
+    lib = _lib
+    rc = fn(*args)
     if rc != MNK_OK:
         detail = _STATUS.get(rc, f"status {rc}")
         if rc == -3:
