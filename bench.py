@@ -44,9 +44,10 @@ PMC_TRAFFIC = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16, help="timed launches of the rollout kernel (chunk plies each)")
-    ap.add_argument("--warmup", type=int, default=2,
-                    help="untimed launches first (2 x 256 plies: the boards reach their stationary fill)")
+    ap.add_argument("--steps", type=int, default=64, help="timed launches of the rollout kernel (chunk plies each)")
+    ap.add_argument("--warmup", type=int, default=64,
+                    help="untimed launches first: the boards reach their stationary fill after ~1 launch, the GPU "
+                         "its sustained clock after ~10 ms of load (the rate climbs ~8 % over the first 50 launches)")
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--board", type=str, default="9x9x5")
     ap.add_argument("--chunk", type=int, default=256,
@@ -244,7 +245,7 @@ def selfplay_mode(args):
         # plies played this step = growth of the move counters (resets restart them at 0 or 1)
         state["plies"] += torch.clamp((env._meta >> 1) - before, min=0).sum()
 
-    steps, warm = min(args.steps * 16, 256), 64  # agent-steps here, not kernel launches
+    steps, warm = min(args.steps * 4, 256), 64  # agent-steps here, not kernel launches
     for t in range(warm):
         step(t)
     state["plies"].zero_()
@@ -347,11 +348,14 @@ def main():
                 main_stream.wait_event(gather_done[slot])  # the buffer is free again
             out = bufs[slot]
             assert t == chunk  # a bench step is a whole chunk
-            if timing[0]:
+            # kernel time: with an exchange step in the loop every launch is bracketed by its own pair of HIP
+            # events (the stream also waits for gathers); on one GPU two events around the whole timed region
+            # do (per-launch pairs cost ~5 % throughput)
+            if timing[0] and mode != "none":
                 ks, ke = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ks.record(main_stream)
             roll.run(t, out=out)
-            if timing[0]:
+            if timing[0] and mode != "none":
                 ke.record(main_stream)
                 kernel_events.append((ks, ke))
             launches += 1
@@ -383,13 +387,16 @@ def main():
     run_steps(args.warmup * chunk)
     barrier()
     timing[0] = True
+    region0, region1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    region0.record(main_stream)
     launches = run_steps(args.steps * chunk)
+    region1.record(main_stream)
     assert launches == args.steps
     barrier()
     dt = time.perf_counter() - t0
-    # time spent inside the rollout kernel only (HIP events on its stream, bracketing each launch)
-    dev_ms = sum(a.elapsed_time(b) for a, b in kernel_events)
+    # time spent in the rollout kernel (HIP events on the stream it is launched on)
+    dev_ms = sum(a.elapsed_time(b) for a, b in kernel_events) if kernel_events else region0.elapsed_time(region1)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
