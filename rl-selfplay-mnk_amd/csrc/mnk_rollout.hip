@@ -199,44 +199,60 @@ k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, 
 // a per-lane VGPR; one DPP swap ORs the verdicts); lane r writes plane r of the records; each lane computes
 // every other Philox block and hands its four words to its partner by DPP.  Move selection and the state
 // update are done redundantly by both lanes (cheaper than exchanging them).  Results are bit-identical to
-// the one-lane kernel.  Measured (9x9x5, 256 plies): 32 768 envs 111 us vs 133 us one-lane; at 65 536 envs
+// the one-lane kernel (all compile-time board geometries).  Measured (9x9x5, 256 plies): 32 768 envs 111 us vs 133 us one-lane; at 65 536 envs
 // it loses, 182 us vs 143 us -- the rollout is VALU-throughput bound (integer VALU ops retire 16 lanes per
 // clock per SIMD, so one wave per SIMD already fills ~80 % of the issue slots) and the pair form executes
-// 1.6x the instructions per env.  The launcher therefore uses it only below 40 960 envs.  Only for compile-time geometries whose largest scan shift is < 32 bits (3x3x3,
-// 9x9x5, 13x13x5), where a per-lane shift is a single v_alignbit_b32 per word.
-// value of the partner lane (lane ^ 1): a DPP quad_perm [1,0,3,2] move, no LDS round trip
+// 1.6x the instructions per env.  The launcher therefore uses it only below 40 960 envs.  // value of the partner lane (lane ^ 1): a DPP quad_perm [1,0,3,2] move, no LDS round trip
 __device__ __forceinline__ uint32_t pair_swap(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
 }
 
-template <int NW>
-__device__ __forceinline__ void bs_shr_lane(uint32_t (&x)[NW], uint32_t s) {  // s < 32, may differ per lane
+// x >>= (role ? S1 : S0): the two lanes of a pair shift by different compile-time amounts.  Where the
+// word parts of the two amounts agree the word move is uniform and only the bit part (one v_alignbit_b32 per
+// word, shift amount in a VGPR) differs per lane; where they differ a per-word select picks the source word.
+template <int NW, int S0, int S1>
+__device__ __forceinline__ void bs_shr_pair(uint32_t (&x)[NW], uint32_t role) {
+  constexpr int Q0 = S0 >> 5, Q1 = S1 >> 5;
+  uint32_t y[NW + 1];
 #pragma unroll
-  for (int w = 0; w < NW; ++w) x[w] = __builtin_amdgcn_alignbit((w + 1 < NW) ? x[w + 1] : 0u, x[w], s);
+  for (int w = 0; w < NW; ++w) {
+    const uint32_t a = (w + Q0 < NW) ? x[w + Q0] : 0u;
+    if (Q0 == Q1) y[w] = a;
+    else y[w] = role ? ((w + Q1 < NW) ? x[w + Q1] : 0u) : a;
+  }
+  y[NW] = 0u;
+  const uint32_t r = role ? (uint32_t)(S1 & 31) : (uint32_t)(S0 & 31);
+#pragma unroll
+  for (int w = 0; w < NW; ++w) x[w] = __builtin_amdgcn_alignbit(y[w + 1], y[w], r);
 }
 
-template <int NW, int CK>
-__device__ __forceinline__ uint32_t bs_run_bits_lane(const uint32_t (&b)[NW], uint32_t d) {
-  uint32_t x[NW], t[NW];
+// run-doubling scan (see bs_has_run) with the direction stride D0 on role 0 and D1 on role 1
+template <int NW, int CK, int D0, int D1, int LEN = 1>
+__device__ __forceinline__ void bs_run_pair_steps(uint32_t (&x)[NW], uint32_t role) {
+  if constexpr (2 * LEN <= CK) {
+    uint32_t t[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t[w] = x[w];
+    bs_shr_pair<NW, LEN * D0, LEN * D1>(t, role);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) x[w] &= t[w];
+    bs_run_pair_steps<NW, CK, D0, D1, 2 * LEN>(x, role);
+  } else if constexpr (LEN < CK) {
+    uint32_t t[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t[w] = x[w];
+    bs_shr_pair<NW, (CK - LEN) * D0, (CK - LEN) * D1>(t, role);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) x[w] &= t[w];
+  }
+}
+
+template <int NW, int CK, int D0, int D1>
+__device__ __forceinline__ uint32_t bs_run_bits_pair(const uint32_t (&b)[NW], uint32_t role) {
+  uint32_t x[NW];
 #pragma unroll
   for (int w = 0; w < NW; ++w) x[w] = b[w];
-  int len = 1;
-#pragma unroll
-  while (2 * len <= CK) {
-#pragma unroll
-    for (int w = 0; w < NW; ++w) t[w] = x[w];
-    bs_shr_lane<NW>(t, (uint32_t)len * d);
-#pragma unroll
-    for (int w = 0; w < NW; ++w) x[w] &= t[w];
-    len *= 2;
-  }
-  if (len < CK) {
-#pragma unroll
-    for (int w = 0; w < NW; ++w) t[w] = x[w];
-    bs_shr_lane<NW>(t, (uint32_t)(CK - len) * d);
-#pragma unroll
-    for (int w = 0; w < NW; ++w) x[w] &= t[w];
-  }
+  bs_run_pair_steps<NW, CK, D0, D1>(x, role);
   uint32_t any = 0;
 #pragma unroll
   for (int w = 0; w < NW; ++w) any |= x[w];
@@ -249,7 +265,6 @@ struct PairLane {
   MnkEnv<NW> e;
   int64_t N;
   uint32_t role;      // 0 / 1 within the pair
-  uint32_t d1, d2;    // this lane's two scan directions
   uint64_t* rp = nullptr;  // rec_planes[t][role][0][env]
   uint32_t* rm = nullptr;  // rec_meta[t][env]
   uint8_t* ra = nullptr;   // act_log[t / 4][env]
@@ -259,8 +274,6 @@ struct PairLane {
   __device__ __forceinline__ PairLane(const MnkGeom& g_, int64_t N_, int64_t env, uint32_t role_,
                                       uint64_t* rec_planes, uint32_t* rec_meta, void* act_log)
       : g(g_), N(N_), role(role_) {
-    d1 = role ? (uint32_t)(CN + 2) : 1u;          // diagonal | row
-    d2 = role ? (uint32_t)CN : (uint32_t)(CN + 1);  // anti-diagonal | column
     if (RECORD) { rp = rec_planes + (int64_t)role * g.W * N + env; rm = rec_meta + env; }
     if (ACT) ra = (uint8_t*)act_log + env * 4;
   }
@@ -290,7 +303,9 @@ struct PairLane {
       e.p[1][w] |= side ? add : 0u;
       mover[w] = side ? e.p[1][w] : e.p[0][w];
     }
-    uint32_t hit = bs_run_bits_lane<NW, CK>(mover, d1) | bs_run_bits_lane<NW, CK>(mover, d2);
+    // role 0 scans columns and rows, role 1 diagonals and anti-diagonals; paired so that the word parts of
+    // the shift amounts agree wherever the board allows (n+1 with n+2, 1 with n)
+    uint32_t hit = bs_run_bits_pair<NW, CK, CN + 1, CN + 2>(mover, role) | bs_run_bits_pair<NW, CK, 1, CN>(mover, role);
     hit |= pair_swap(hit);  // the partner's two directions
     const uint32_t win = hit ? 1u : 0u;
     const uint32_t moves = (e.meta >> 1) + 1u;
@@ -421,7 +436,8 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
     pair_override = v ? atoi(v) : -1;
   }
   const bool pair_geom = (g.n == 9 && g.k == 5 && g.NW == 3) || (g.n == 3 && g.k == 3 && g.NW == 1) ||
-                         (g.n == 13 && g.k == 5 && g.NW == 6);
+                         (g.n == 13 && g.k == 5 && g.NW == 6) || (g.n == 15 && g.k == 5 && g.NW == 8) ||
+                         (g.n == 19 && g.k == 5 && g.NW == 12);
   const bool use_pair = pair_geom && act_bytes != 2 &&
                         (pair_override >= 0 ? pair_override != 0 : N <= 40960);
   const bool rec = rec_planes && rec_meta;
@@ -435,7 +451,9 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   do {                                                         \
     if (g.n == 9) MNK_PAIR(3, 9, 5, REC, ACTB);                \
     else if (g.n == 3) MNK_PAIR(1, 3, 3, REC, ACTB);           \
-    else MNK_PAIR(6, 13, 5, REC, ACTB);                        \
+    else if (g.n == 13) MNK_PAIR(6, 13, 5, REC, ACTB);         \
+    else if (g.n == 15) MNK_PAIR(8, 15, 5, REC, ACTB);         \
+    else MNK_PAIR(12, 19, 5, REC, ACTB);                       \
   } while (0)
     if (rec && act_bytes == 1) MNK_PAIR_GEOM(true, 1);
     else if (rec) MNK_PAIR_GEOM(true, 0);
