@@ -29,6 +29,9 @@ for p in (ROOT, os.path.join(ROOT, "rl-selfplay-mnk_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# multi-process GPU work on this pool needs dmabuf IPC; must be in the environment before HIP initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -308,7 +311,6 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
