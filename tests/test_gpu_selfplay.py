@@ -559,3 +559,72 @@ def test_packed_rollout_buffer_equals_the_dense_one(hip, m, n, k):
     with pytest.raises(IndexError, match="Buffer was full."):
         for _ in range(3):
             packed.add(pobs, acts, rew, val, lp, term)
+
+
+def test_reference_network_end_to_end(hip, golden_dir):
+    """G6: a reference net (cnn_b_s, seed-0 weights stored as data) fed by the HIP path.  The canonical
+    observation and mask built by the kernels are bit-identical to the reference's; the same weights on the GPU
+    give the reference's masked log-probabilities and values within 1e-5 (fp32, eval mode; the only difference is
+    MIOpen vs MKL-DNN summation order); NNPolicy / FusedNNPolicy pick the reference's argmax wherever its top-2
+    gap exceeds 1e-4."""
+    import torch.nn as nn
+
+    g = np.load(f"{golden_dir}/policy_cnn_b_s.npz")
+    m, n, k, nenv, c = 9, 9, 5, 64, 81
+
+    class CnnBS(nn.Module):  # the layer list of the reference's cnn_b_s (alg/architectures/cnn.py:8-60, configs.py:49-56)
+        def __init__(self):
+            super().__init__()
+            body, cin = [], 2
+            for _ in range(4):
+                body += [nn.Conv2d(cin, 56, 3, padding=1), nn.BatchNorm2d(56), nn.ReLU()]
+                cin = 56
+            self.shared_body = nn.Sequential(*body)
+            self.actor = nn.Sequential(nn.Conv2d(56, 2, 1), nn.Flatten(), nn.LayerNorm(2 * c), nn.ReLU(),
+                                       nn.Linear(2 * c, 128), nn.LayerNorm(128), nn.ReLU(), nn.Linear(128, c))
+            self.critic = nn.Sequential(nn.Conv2d(56, 1, 1), nn.Flatten(), nn.LayerNorm(c), nn.ReLU(),
+                                        nn.Linear(c, 128), nn.LayerNorm(128), nn.ReLU(), nn.Linear(128, 1), nn.Tanh())
+
+        def forward(self, obs, action_mask=None):
+            f = self.shared_body(obs)
+            logits, value = self.actor(f), self.critic(f)
+            if action_mask is not None:  # cnn.py:69-79
+                logits = torch.where(action_mask.bool(), logits, torch.full_like(logits, -torch.inf))
+                dead = logits.max(dim=1, keepdim=True)[0] == -torch.inf
+                logits = torch.where(dead, torch.zeros_like(logits), logits)
+            return torch.distributions.Categorical(logits=logits), value
+
+    net = CnnBS()
+    net.load_state_dict({key[len("param/"):]: torch.from_numpy(g[key]) for key in g.files if key.startswith("param/")})
+    net = net.to(DEV).eval()
+
+    env = hip.Env(m, n, k, nenv, device=DEV)
+    env.boards = torch.from_numpy(unpack_boards(g["planes"], m, n))
+    env.current_player = torch.from_numpy(g["meta_side"].astype(np.int64))
+    env.move_counts = torch.from_numpy(g["meta_moves"].astype(np.int64))
+    wrap = hip.Wrapper(env)
+    wrap.agent_side.copy_(torch.from_numpy(g["agent_side"].astype(np.int64)))
+    obs = wrap.get_agent_obs()
+    assert np.array_equal(pack_boards(obs["observation"].cpu().numpy(), m, n), g["obs_planes"])
+    assert np.array_equal(pack_cells(obs["action_mask"].cpu().numpy(), m, n), g["obs_mask"])
+
+    prev = torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cudnn.allow_tf32 = torch.backends.cuda.matmul.allow_tf32 = False
+    try:
+        with torch.no_grad():
+            dist, value = net(obs["observation"], obs["action_mask"])
+        logp, want = dist.logits.cpu().numpy(), g["logp"]
+        legal = np.isfinite(want)
+        assert np.array_equal(np.isfinite(logp), legal)
+        assert np.abs(logp[legal] - want[legal]).max() < 1e-5
+        assert np.abs(value.cpu().numpy() - g["value"]).max() < 1e-5
+        top2 = np.sort(np.where(legal, want, -np.inf), axis=1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 1e-4
+        assert clear.sum() > 32
+        for policy in (hip.policy.NNPolicy(net), hip.policy.FusedNNPolicy(net, seed=0)):
+            act = policy.act(obs, deterministic=True).cpu().numpy()
+            assert np.array_equal(act[clear], g["argmax"][clear])
+            act = policy.act(obs).cpu().numpy()  # sampled actions are legal
+            assert legal[np.arange(nenv), act].all()
+    finally:
+        torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32 = prev

@@ -126,3 +126,19 @@ def test_oracle_env_equals_reference(case):
 @pytest.mark.parametrize("case", SELFPLAY_CASES[:6])
 def test_oracle_selfplay_equals_reference(case):
     assert check_selfplay(*case)
+
+
+def test_oracle_canonical_view_of_policy_fixture(golden_dir):
+    """G6 fixture: the oracle's canonical observation of the stored position equals what the reference handed
+    to its network."""
+    g = np.load(f"{golden_dir}/policy_cnn_b_s.npz")
+    env = OracleVectorEnv(9, 9, 5, 64)
+    env.boards.copy_(torch.from_numpy(unpack_boards(g["planes"], 9, 9)))
+    env.current_player.copy_(torch.from_numpy(g["meta_side"].astype(np.int64)))
+    env.move_counts.copy_(torch.from_numpy(g["meta_moves"].astype(np.int64)))
+    wrap = OracleSelfPlay(env)
+    wrap.agent_side.copy_(torch.from_numpy(g["agent_side"].astype(np.int64)))
+    obs = wrap.canonical_obs()
+    assert np.array_equal(pack_boards(obs["observation"].numpy(), 9, 9), g["obs_planes"])
+    assert np.array_equal(pack_cells(obs["action_mask"].numpy(), 9, 9), g["obs_mask"])
+    assert np.isfinite(g["logp"]).sum(axis=1).tolist() == obs["action_mask"].sum(dim=1).tolist()
