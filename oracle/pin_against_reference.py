@@ -10,7 +10,7 @@ and every output after *every* operation, bit for bit:
     opponents, fixed and drawn sides) under the same ``torch.manual_seed``.
 
 The reference tree never travels to the GPU box, so nothing here is imported by
-the GPU tests; ``tests/test_oracle_pin.py`` runs it when the tree is present and
+the GPU tests; ``tests/test_oracle_golden.py`` runs it (fixed cases + a hypothesis property test) when the tree is present and
 the golden fixtures cover the rest.
 
 Usage:  python -m oracle.pin_against_reference
@@ -84,8 +84,9 @@ def check_env(m, n, k, nenv, steps, seed, illegal_rate=0.15, subset_rate=0.5):
         anycell = torch.randint(-c, c, (nenv,), generator=g)  # includes negatives: torch wraps them
         use_any = torch.rand(nenv, generator=g) < illegal_rate
         acts = torch.where(use_any, anycell, legal)
-        if torch.rand((), generator=g) < subset_rate:
-            keep = torch.rand(nenv, generator=g) < 0.6
+        keep = torch.rand(nenv, generator=g) < 0.6
+        # (the reference cannot step an empty subset -- view(0, -1) raises -- and none of its callers does)
+        if torch.rand((), generator=g) < subset_rate and bool(keep.any()):
             idx = torch.nonzero(keep).squeeze(1)
             o1, r1, d1 = ref.step_subset(acts[idx], idx)
             o2, r2, d2 = ora.step_subset(acts[idx], idx)

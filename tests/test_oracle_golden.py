@@ -142,3 +142,20 @@ def test_oracle_canonical_view_of_policy_fixture(golden_dir):
     assert np.array_equal(pack_boards(obs["observation"].numpy(), 9, 9), g["obs_planes"])
     assert np.array_equal(pack_cells(obs["action_mask"].numpy(), 9, 9), g["obs_mask"])
     assert np.isfinite(g["logp"]).sum(axis=1).tolist() == obs["action_mask"].sum(dim=1).tolist()
+
+
+@pytest.mark.skipif(not reference_available(), reason="reference tree not mounted (GPU box)")
+def test_oracle_equals_reference_on_random_geometries():
+    """Property test: random board shapes, batch sizes and seeds; oracle == imported
+    reference after every operation, env and wrapper."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+
+    @settings(max_examples=12, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(m=st.integers(2, 12), n=st.integers(2, 12), kk=st.integers(1, 6), nenv=st.integers(1, 24),
+           seed=st.integers(0, 10 ** 6))
+    def run(m, n, kk, nenv, seed):
+        k = min(kk, m, n)
+        assert check_env(m, n, k, nenv, 3 * max(m, n), seed)
+        assert check_selfplay(m, n, k, nenv, 2 * max(m, n), seed, "random" if seed % 2 else "hash", None)
+
+    run()
