@@ -118,11 +118,16 @@ int mnk_observe(const uint64_t* planes, const uint32_t* meta, int64_t N, int m, 
 int mnk_pack_boards(const float* boards, uint64_t* planes, int64_t N, int m, int n, void* stream);
 int mnk_unpack_boards(const uint64_t* planes, float* boards, int64_t N, int m, int n, void* stream);
 
+/* `step_dev` (functions that draw random numbers): optional device pointer to a u64 that is ADDED to `step`.
+ * A captured hipGraph replays its kernel arguments verbatim; keeping the advancing part of the Philox step
+ * counter in device memory (bumped by one more node of the graph) lets a captured agent-step be replayed.
+ * NULL = the step is `step`. */
+
 /* ---- selfplay/policy.py:13-29 RandomPolicy.act -------------------------------------------
  * One uniformly drawn legal cell per env, from Philox(seed, env_id0 + i, step, stream_id).
  * Rows without a legal cell draw uniformly over all cells (the 1e-8 guard of policy.py:21-24). */
 int mnk_sample_legal(const uint64_t* planes, int64_t N, int m, int n, uint64_t seed, uint64_t step,
-                     int64_t env_id0, int stream_id, int64_t* actions, void* stream);
+                     const uint64_t* step_dev, int64_t env_id0, int stream_id, int64_t* actions, void* stream);
 
 /* ---- alg/architectures/cnn.py:69-79 (= resnet.py:84-95, transformer.py:80-91) + policy.py:46-52
  * Masked categorical head fused with the draw: logits f32[N][C] (any additive normalisation),
@@ -131,8 +136,8 @@ int mnk_sample_legal(const uint64_t* planes, int64_t N, int m, int n, uint64_t s
  * All-masked row -> uniform over C (cnn.py:76-77).
  * logp (optional) = log-probability of the chosen action under the masked softmax. */
 int mnk_sample_logits(const float* logits, const uint8_t* mask, int64_t N, int C, uint64_t seed,
-                      uint64_t step, int64_t env_id0, int deterministic, int64_t* actions, float* logp,
-                      void* stream);
+                      uint64_t step, const uint64_t* step_dev, int64_t env_id0, int deterministic,
+                      int64_t* actions, float* logp, void* stream);
 
 /* ---- selfplay/torch_self_play_wrapper.py:32-67 step(), split around the opponent forward ----
  * pre : envs with pending != 0 are reset instead of stepped (their action is ignored), get a
@@ -145,8 +150,8 @@ int mnk_sample_logits(const float* logits, const uint8_t* mask, int64_t N, int C
  *       writes the agent's canonical observation and mask (wrapper:99-112). */
 int mnk_selfplay_pre(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k,
                      const int64_t* actions, const uint8_t* pending, int64_t* agent_side,
-                     const int64_t* forced_side, uint64_t seed, uint64_t step, int64_t env_id0,
-                     float* rewards, uint8_t* terminated, uint8_t* sp_flags,
+                     const int64_t* forced_side, uint64_t seed, uint64_t step, const uint64_t* step_dev,
+                     int64_t env_id0, float* rewards, uint8_t* terminated, uint8_t* sp_flags,
                      float* opp_obs, uint8_t* opp_mask, int32_t* err, void* stream);
 int mnk_selfplay_post(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k,
                       const int64_t* opp_actions, const uint8_t* sp_flags, const int64_t* agent_side,
@@ -162,8 +167,8 @@ int mnk_selfplay_post(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n,
  * pre + Philox legal draw (stream OPP) + post. */
 int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k,
                              const int64_t* actions, uint8_t* pending, int64_t* agent_side,
-                             const int64_t* forced_side, uint64_t seed, uint64_t step, int64_t env_id0,
-                             float* rewards, uint8_t* terminated, float* obs, uint8_t* legal_mask,
+                             const int64_t* forced_side, uint64_t seed, uint64_t step, const uint64_t* step_dev,
+                             int64_t env_id0, float* rewards, uint8_t* terminated, float* obs, uint8_t* legal_mask,
                              int32_t* err, float* ep_return, int32_t* ep_length, int64_t* ep_stats,
                              void* stream);
 

@@ -131,10 +131,11 @@ __global__ void k_pack_boards(MnkGeom g, const float* boards, uint64_t* planes, 
 // ------------------------------------------------------------------ RandomPolicy
 template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
-k_sample_legal(MnkGeom g, const uint64_t* planes, int64_t N, uint64_t seed, uint64_t step, int64_t env_id0,
-               uint32_t stream_id, int64_t* actions) {
+k_sample_legal(MnkGeom g, const uint64_t* planes, int64_t N, uint64_t seed, uint64_t step, const uint64_t* step_dev,
+               int64_t env_id0, uint32_t stream_id, int64_t* actions) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
+  if (step_dev) step += *step_dev;  // device-resident part of the step counter (graph replays)
   MnkEnv<NW> e;
   plane_load<NW>(e.p[0], planes, N, g.W, i);
   plane_load<NW>(e.p[1], planes + (int64_t)g.W * N, N, g.W, i);
@@ -208,9 +209,10 @@ template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
 k_selfplay_pre(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions,
                const uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
-               uint64_t step, int64_t env_id0, float* rewards, uint8_t* terminated, uint8_t* sp_flags,
-               float* opp_obs, uint8_t* opp_mask, int32_t* err, int vec_ok, int envs_per_block) {
+               uint64_t step, const uint64_t* step_dev, int64_t env_id0, float* rewards, uint8_t* terminated,
+               uint8_t* sp_flags, float* opp_obs, uint8_t* opp_mask, int32_t* err, int vec_ok, int envs_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  if (step_dev) step += *step_dev;
   const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
   const int64_t env0 = (int64_t)blockIdx.x * B;
   const int64_t i = env0 + tid;
@@ -302,9 +304,11 @@ template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
 k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions,
                        uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
-                       uint64_t step, int64_t env_id0, float* rewards, uint8_t* terminated, float* obs,
-                       uint8_t* legal_mask, int32_t* err, MnkEpisodes ep, int vec_ok, int envs_per_block) {
+                       uint64_t step, const uint64_t* step_dev, int64_t env_id0, float* rewards,
+                       uint8_t* terminated, float* obs, uint8_t* legal_mask, int32_t* err, MnkEpisodes ep,
+                       int vec_ok, int envs_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  if (step_dev) step += *step_dev;
   __shared__ unsigned int lds_ep[MNK_STATS_COUNTERS];
   const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
   const int64_t env0 = (int64_t)blockIdx.x * B;
@@ -390,8 +394,9 @@ __device__ __forceinline__ float half_sum(float v) {
 template <int K>
 __global__ void __launch_bounds__(64)
 k_sample_logits(const float* logits, const uint8_t* mask, int64_t N, int C, uint64_t seed, uint64_t step,
-                int64_t env_id0, int deterministic, int64_t* actions, float* logp) {
+                const uint64_t* step_dev, int64_t env_id0, int deterministic, int64_t* actions, float* logp) {
   const int lane = threadIdx.x, half = lane >> 5, sub = lane & 31;
+  if (step_dev) step += *step_dev;
   const int64_t row = (int64_t)blockIdx.x * 2 + half;
   const bool live = row < N;
   const int64_t i = live ? row : N - 1;
@@ -713,8 +718,8 @@ int mnk_step(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, c
   return MNK_OK;
 }
 
-int mnk_sample_legal(const uint64_t* planes, int64_t N, int m, int n, uint64_t seed, uint64_t step, int64_t env_id0,
-                     int stream_id, int64_t* actions, void* stream) {
+int mnk_sample_legal(const uint64_t* planes, int64_t N, int m, int n, uint64_t seed, uint64_t step,
+                     const uint64_t* step_dev, int64_t env_id0, int stream_id, int64_t* actions, void* stream) {
   MnkGeom g;
   int rc = mnk_geom_any_k(m, n, &g);
   if (rc != MNK_OK) return rc;
@@ -723,14 +728,14 @@ int mnk_sample_legal(const uint64_t* planes, int64_t N, int m, int n, uint64_t s
   const int B = 64;
   const dim3 grid((unsigned)((N + B - 1) / B));
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_sample_legal), grid, dim3(B), 0, (hipStream_t)stream, g, planes, N, seed,
-                                         step, env_id0, (uint32_t)stream_id, actions));
+                                         step, step_dev, env_id0, (uint32_t)stream_id, actions));
   return mnk_launch_status("sample_legal");
 }
 
 int mnk_selfplay_pre(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const int64_t* actions,
                      const uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
-                     uint64_t step, int64_t env_id0, float* rewards, uint8_t* terminated, uint8_t* sp_flags,
-                     float* opp_obs, uint8_t* opp_mask, int32_t* err, void* stream) {
+                     uint64_t step, const uint64_t* step_dev, int64_t env_id0, float* rewards, uint8_t* terminated,
+                     uint8_t* sp_flags, float* opp_obs, uint8_t* opp_mask, int32_t* err, void* stream) {
   MnkGeom g;
   int rc = mnk_check_geom(m, n, k, &g);
   if (rc != MNK_OK) return rc;
@@ -743,8 +748,8 @@ int mnk_selfplay_pre(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, 
   const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B) : 0;
   const dim3 grid((unsigned)((N + B - 1) / B));
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_pre), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, planes, meta,
-                                         N, actions, pending, agent_side, forced_side, seed, step, env_id0, rewards,
-                                         terminated, sp_flags, opp_obs, opp_mask, err, vec_ok, B));
+                                         N, actions, pending, agent_side, forced_side, seed, step, step_dev, env_id0,
+                                         rewards, terminated, sp_flags, opp_obs, opp_mask, err, vec_ok, B));
   return mnk_launch_status("selfplay_pre");
 }
 
@@ -773,9 +778,9 @@ int mnk_selfplay_post(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n,
 
 int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const int64_t* actions,
                              uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
-                             uint64_t step, int64_t env_id0, float* rewards, uint8_t* terminated, float* obs,
-                             uint8_t* legal_mask, int32_t* err, float* ep_return, int32_t* ep_length,
-                             int64_t* ep_stats, void* stream) {
+                             uint64_t step, const uint64_t* step_dev, int64_t env_id0, float* rewards,
+                             uint8_t* terminated, float* obs, uint8_t* legal_mask, int32_t* err, float* ep_return,
+                             int32_t* ep_length, int64_t* ep_stats, void* stream) {
   MnkGeom g;
   int rc = mnk_check_geom(m, n, k, &g);
   if (rc != MNK_OK) return rc;
@@ -790,19 +795,20 @@ int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m,
   const dim3 grid((unsigned)((N + B - 1) / B));
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_step_random), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g,
                                          planes, meta, N, actions, pending, agent_side, forced_side, seed, step,
-                                         env_id0, rewards, terminated, obs, legal_mask, err, ep, vec_ok, B));
+                                         step_dev, env_id0, rewards, terminated, obs, legal_mask, err, ep, vec_ok, B));
   return mnk_launch_status("selfplay_step_random");
 }
 
 int mnk_sample_logits(const float* logits, const uint8_t* mask, int64_t N, int C, uint64_t seed, uint64_t step,
-                      int64_t env_id0, int deterministic, int64_t* actions, float* logp, void* stream) {
+                      const uint64_t* step_dev, int64_t env_id0, int deterministic, int64_t* actions, float* logp,
+                      void* stream) {
   if (!logits || !mask || !actions || N < 0 || C < 1 || C > 32 * SAMPLE_MAX_K) return MNK_EINVAL;
   if (N == 0) return MNK_OK;
   if (N > 0x7fffffffLL) return MNK_EINVAL;
   const dim3 grid((unsigned)((N + 1) / 2));
 #define MNK_SAMPLE(KV)                                                                                             \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_logits<KV>), grid, dim3(64), 0, (hipStream_t)stream, logits, mask, N, \
-                     C, seed, step, env_id0, deterministic, actions, logp)
+                     C, seed, step, step_dev, env_id0, deterministic, actions, logp)
   switch ((C + 31) / 32) {  // cells per lane
     case 1: MNK_SAMPLE(1); break;
     case 2: MNK_SAMPLE(2); break;

@@ -328,7 +328,7 @@ class TorchVectorMnkEnv:
         """Uniform legal action per env (the reference's ``RandomPolicy``, policy.py:13-29) from Philox."""
         if self.num_envs:
             mnk_hip.call("mnk_sample_legal", mnk_hip.ptr(self._planes), self.num_envs, self.m, self.n, seed, step,
-                         env_id0, stream_id, mnk_hip.ptr(actions), self._stream())
+                         None, env_id0, stream_id, mnk_hip.ptr(actions), self._stream())
 
     def reset_mask_(self, mask_u8) -> None:
         """Fixed-shape reset: envs with a non-zero byte in ``mask_u8`` (bool / uint8, (N,)) start over."""

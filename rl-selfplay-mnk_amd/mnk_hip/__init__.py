@@ -38,14 +38,14 @@ SIGNATURES = {
     "mnk_observe": [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp],
     "mnk_pack_boards": [_vp, _vp, _i64, _i, _i, _vp],
     "mnk_unpack_boards": [_vp, _vp, _i64, _i, _i, _vp],
-    "mnk_sample_legal": [_vp, _i64, _i, _i, _u64, _u64, _i64, _i, _vp, _vp],
-    "mnk_sample_logits": [_vp, _vp, _i64, _i, _u64, _u64, _i64, _i, _vp, _vp, _vp],
-    "mnk_selfplay_pre": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _u64, _u64, _i64, _vp, _vp, _vp, _vp, _vp,
-                         _vp, _vp],
+    "mnk_sample_legal": [_vp, _i64, _i, _i, _u64, _u64, _vp, _i64, _i, _vp, _vp],
+    "mnk_sample_logits": [_vp, _vp, _i64, _i, _u64, _u64, _vp, _i64, _i, _vp, _vp, _vp],
+    "mnk_selfplay_pre": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _vp, _vp, _vp,
+                         _vp, _vp, _vp],
     "mnk_selfplay_post": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                           _vp],
-    "mnk_selfplay_step_random": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _u64, _u64, _i64, _vp, _vp, _vp,
-                                 _vp, _vp, _vp, _vp, _vp, _vp],
+    "mnk_selfplay_step_random": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _vp,
+                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mnk_rollout_random": [_vp, _vp, _i64, _i, _i, _i, _i, _u64, _u64, _i64, _vp, _vp, _vp, _vp, _i, _vp],
     "mnk_replay_actions": [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "mnk_unpack_records": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

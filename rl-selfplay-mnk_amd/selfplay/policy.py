@@ -30,6 +30,7 @@ class _HipSampler:
     def __init__(self, seed=None):
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
         self.calls = 0
+        self.step_dev = None  # optional device int64[1] added to the step counter (graph replays)
 
     def draw(self, logits, mask, deterministic, want_logp=False):
         mask = mask.contiguous()
@@ -42,10 +43,11 @@ class _HipSampler:
         actions = torch.empty(b, dtype=torch.long, device=mask.device)
         logp = torch.empty(b, dtype=torch.float32, device=mask.device) if want_logp else None
         if b:
-            mnk_hip.call("mnk_sample_logits", mnk_hip.ptr(logits), mnk_hip.ptr(mask), b, c, self.seed, self.calls, 0,
-                         1 if deterministic else 0, mnk_hip.ptr(actions), mnk_hip.ptr(logp),
-                         mnk_hip.stream_ptr(mask.device))
-        self.calls += 1
+            mnk_hip.call("mnk_sample_logits", mnk_hip.ptr(logits), mnk_hip.ptr(mask), b, c, self.seed, self.calls,
+                         mnk_hip.ptr(self.step_dev), 0, 1 if deterministic else 0, mnk_hip.ptr(actions),
+                         mnk_hip.ptr(logp), mnk_hip.stream_ptr(mask.device))
+        if self.step_dev is None:
+            self.calls += 1
         return (actions, logp) if want_logp else actions
 
 

@@ -52,6 +52,7 @@ class TorchSelfPlayWrapper:
         self._flags = torch.zeros(self.num_envs, dtype=torch.uint8, device=self._dev)
         self._no_actions = torch.zeros(self.num_envs, dtype=torch.long, device=self._dev)
         self._ep_return = self._ep_length = self._ep_stats = None  # see track_episodes()
+        self.step_dev = None  # optional device int64[1] added to step_count inside the kernels (graph replays)
 
     def set_opponent(self, policy):  # reference wrapper:16-17
         self.opponent_policy = policy
@@ -140,7 +141,8 @@ class TorchSelfPlayWrapper:
         rewards = torch.empty(n, dtype=torch.float32, device=dev)
         terminated = torch.empty(n, dtype=torch.bool, device=dev)
         step = self.step_count
-        self.step_count += 1
+        if self.step_dev is None:
+            self.step_count += 1
         opp = self.opponent_policy
         if n == 0:
             return {"observation": obs, "action_mask": mask}, rewards, terminated, torch.zeros_like(terminated), {}
@@ -149,7 +151,8 @@ class TorchSelfPlayWrapper:
             # RandomPolicy opponent: the whole step is one launch
             mnk_hip.call("mnk_selfplay_step_random", mnk_hip.ptr(env._planes), mnk_hip.ptr(env._meta), n, env.m,
                          env.n, env.k, mnk_hip.ptr(actions), mnk_hip.ptr(self.pending_resets),
-                         mnk_hip.ptr(self.agent_side), mnk_hip.ptr(forced), self.seed, step, self.env_id0,
+                         mnk_hip.ptr(self.agent_side), mnk_hip.ptr(forced), self.seed, step,
+                         mnk_hip.ptr(self.step_dev), self.env_id0,
                          mnk_hip.ptr(rewards), mnk_hip.ptr(terminated), mnk_hip.ptr(obs), mnk_hip.ptr(mask),
                          mnk_hip.ptr(env._err), mnk_hip.ptr(self._ep_return), mnk_hip.ptr(self._ep_length),
                          mnk_hip.ptr(self._ep_stats), env._stream())
@@ -160,7 +163,8 @@ class TorchSelfPlayWrapper:
             opp_mask = torch.empty((n, env.max_moves), dtype=torch.bool, device=dev)
             mnk_hip.call("mnk_selfplay_pre", mnk_hip.ptr(env._planes), mnk_hip.ptr(env._meta), n, env.m, env.n,
                          env.k, mnk_hip.ptr(actions), mnk_hip.ptr(self.pending_resets), mnk_hip.ptr(self.agent_side),
-                         mnk_hip.ptr(forced), self.seed, step, self.env_id0, mnk_hip.ptr(rewards),
+                         mnk_hip.ptr(forced), self.seed, step, mnk_hip.ptr(self.step_dev), self.env_id0,
+                         mnk_hip.ptr(rewards),
                          mnk_hip.ptr(terminated), mnk_hip.ptr(self._flags), mnk_hip.ptr(opp_obs),
                          mnk_hip.ptr(opp_mask), mnk_hip.ptr(env._err), env._stream())
             with torch.no_grad():  # wrapper:91-94: one positional argument, no `deterministic`

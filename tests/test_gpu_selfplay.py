@@ -628,3 +628,61 @@ def test_reference_network_end_to_end(hip, golden_dir):
             assert legal[np.arange(nenv), act].all()
     finally:
         torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32 = prev
+
+
+@pytest.mark.parametrize("opponent", ["random", "nn"])
+def test_graphed_agent_step_equals_eager(hip, opponent):
+    """selfplay/graphed.py: the captured hipGraph of (net -> fused draw -> wrapper.step) replays to exactly
+    what the same sequence does eagerly, step after step (the Philox step counter advances on the device)."""
+    import copy
+
+    import torch.nn as nn
+
+    from selfplay.graphed import GraphedAgentStep
+
+    m, n, k, nenv, c = 3, 3, 3, 384, 9
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.body = nn.Sequential(nn.Flatten(), nn.Linear(2 * c, 64), nn.Tanh())
+            self.pi, self.v = nn.Linear(64, c), nn.Linear(64, 1)
+
+        def forward(self, obs, action_mask=None):
+            h = self.body(obs)
+            logits = self.pi(h)
+            if action_mask is not None:
+                logits = torch.where(action_mask.bool(), logits, torch.full_like(logits, -torch.inf))
+            return torch.distributions.Categorical(logits=logits, validate_args=False), torch.tanh(self.v(h))
+
+    torch.manual_seed(0)
+    net = Net().to(DEV).eval()
+    opp_net = Net().to(DEV).eval()
+
+    def make():
+        w = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV), seed=5)
+        w.set_opponent(hip.policy.RandomPolicy(c, seed=3) if opponent == "random"
+                       else hip.policy.FusedNNPolicy(copy.deepcopy(opp_net), seed=3))
+        return w
+
+    graphed = GraphedAgentStep(make(), net, seed=11)
+    # eager twin: same seeds, the step counters passed by value
+    w = make()
+    obs, _ = w.reset()
+    sampler = hip.policy._HipSampler(seed=11)
+    warm = int(graphed.step_dev.item())   # steps the collector already played while warming up / capturing
+    for t in range(warm + 40):
+        with torch.no_grad():
+            dist, values = net(obs["observation"], None)
+        if opponent == "nn":
+            w.opponent_policy._sampler.calls = t + 1  # the reset's reply used draw 0
+        sampler.calls = t
+        actions, logp = sampler.draw(dist.logits, obs["action_mask"], False, want_logp=True)
+        prev = obs
+        obs, rew, term, trunc, _ = w.step(actions)
+        if t >= warm:
+            out = graphed.step()
+            assert torch.equal(out["obs"], prev["observation"]) and torch.equal(out["mask"], prev["action_mask"]), t
+            assert torch.equal(out["actions"], actions) and torch.equal(out["rewards"], rew), t
+            assert torch.equal(out["terminated"], term) and torch.allclose(out["log_probs"], logp), t
+    assert torch.equal(graphed.current_obs()["observation"], obs["observation"])
