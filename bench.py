@@ -114,8 +114,17 @@ def cpu_baseline(env, seconds, threads=0):
         obs = one(obs)
         steps += 1
     dt = time.perf_counter() - t0
+    # one-thread figure, a short sample
+    torch.set_num_threads(1)
+    steps1, t1 = 0, time.perf_counter()
+    while time.perf_counter() - t1 < min(6.0, seconds):
+        obs = one(obs)
+        steps1 += 1
+    dt1 = time.perf_counter() - t1
+    torch.set_num_threads(threads)
     return {
         "value": steps * n / dt,
+        "single_thread_value": steps1 * n / dt1,
         "unit": "env-steps/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
