@@ -310,8 +310,7 @@ def main():
 
     import mnk_hip
     from env.torch_vector_mnk_env import TorchVectorMnkEnv
-    from selfplay.random_rollout import (GatheredLogs, RandomRollout, RolloutRecords, action_log_dtype,
-                                         gather_action_logs, replay_shard)
+    from selfplay.random_rollout import GatheredLogs, RandomRollout, gather_action_logs
 
     mnk_hip.load()
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())

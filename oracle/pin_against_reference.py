@@ -18,7 +18,6 @@ Usage:  python -m oracle.pin_against_reference
 import os
 import sys
 
-import numpy as np
 import torch
 
 REFERENCE_SRC = "/root/reference/src"

@@ -6,7 +6,7 @@ import torch
 
 from oracle import philox
 from oracle.env_torch import OracleVectorEnv
-from oracle.packing import pack_boards, pack_cells
+from oracle.packing import pack_boards
 from oracle.rollout import random_rollout
 from oracle.rollout import replay_actions as oracle_replay
 from replay import golden_files, play_scenario, replay_env_log

@@ -1,6 +1,6 @@
 """Per-kernel timings of the API-level kernels at a given shape (developer tool, GPU box).
 Prints achieved algorithmic GB/s per SURVEY.md section 8d byte counts."""
-import os, sys, time
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "rl-selfplay-mnk_amd")]
 import torch

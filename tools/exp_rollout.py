@@ -1,5 +1,5 @@
 """Timing experiments for the fused rollout kernel (developer tool, GPU box)."""
-import os, sys, time
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "rl-selfplay-mnk_amd")]
 import torch
