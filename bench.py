@@ -428,6 +428,23 @@ def main():
             dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
             rdt = float(rmax.item())
         reps.append(world * nenv * plies / rdt)
+    # for the decomposition: the same K launches with the exchange step switched off (compute only)
+    compute_only = None
+    if mode != "none":
+        def run_compute_only(total):
+            done = 0
+            while done < total:
+                roll.run(chunk, out=bufs[(done // chunk) & 1])
+                done += chunk
+
+        barrier()
+        c0 = time.perf_counter()
+        run_compute_only(args.steps * chunk)
+        barrier()
+        cdt = time.perf_counter() - c0
+        cmax = torch.tensor([cdt], dtype=torch.float64, device=dev)
+        dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+        compute_only = world * nenv * plies / float(cmax.item())
     words = env.words
     # roofline of the dominant kernel (mnk_rollout_random): algorithmic bytes per launch / avg launch time
     plies_per_launch = chunk
@@ -443,6 +460,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt * 1e3 / args.steps,
+        "value_without_exchange": compute_only,
         "repetitions": {"values": reps, "median": sorted(reps)[len(reps) // 2], "min": min(reps), "max": max(reps)},
         "step_definition": f"one launch of the fused rollout kernel = {chunk} plies on each of {nenv} envs per GPU",
         "higher_is_better": True,
