@@ -269,20 +269,20 @@ struct PairLane {
   uint64_t* rp = nullptr;  // rec_planes[t][role][0][env]
   uint32_t* rm = nullptr;  // rec_meta[t][env]
   uint8_t* ra = nullptr;   // act_log[t / 4][env]
-  uint32_t quad = 0;
+  uint64_t quad = 0;       // four actions, 8 or 16 bits each (ACT = 1 / 2)
   uint32_t acc_done_draw = 0, acc_black_white = 0, len_sum = 0;
 
   __device__ __forceinline__ PairLane(const MnkGeom& g_, int64_t N_, int64_t env, uint32_t role_,
                                       uint64_t* rec_planes, uint32_t* rec_meta, void* act_log)
       : g(g_), N(N_), role(role_) {
     if (RECORD) { rp = rec_planes + (int64_t)role * g.W * N + env; rm = rec_meta + env; }
-    if (ACT) ra = (uint8_t*)act_log + env * 4;
+    if (ACT) ra = (uint8_t*)act_log + env * 4 * ACT;
   }
 
   __device__ __forceinline__ void ply(uint32_t x, int field) {
     const int a = env_pick_legal<NW, CN>(g, e, x);
     if (ACT) {
-      quad |= (uint32_t)a << (8 * field);
+      quad |= (uint64_t)(uint32_t)a << (8 * ACT * field);
       if (field == 3) flush_log();
     }
     if (RECORD) {  // lane `role` writes plane `role` of the board before the ply
@@ -322,9 +322,10 @@ struct PairLane {
     if (done) env_clear<NW>(e);
   }
 
-  __device__ __forceinline__ void flush_log() {
-    *(uint32_t*)ra = quad;  // both lanes, same word
-    ra += N * 4;
+  __device__ __forceinline__ void flush_log() {  // both lanes write the same word
+    if (ACT == 1) *(uint32_t*)ra = (uint32_t)quad;
+    if (ACT == 2) *(uint64_t*)ra = quad;
+    ra += N * 4 * ACT;
     quad = 0;
   }
 };
@@ -439,7 +440,7 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   const bool pair_geom = (g.n == 9 && g.k == 5 && g.NW == 3) || (g.n == 3 && g.k == 3 && g.NW == 1) ||
                          (g.n == 13 && g.k == 5 && g.NW == 6) || (g.n == 15 && g.k == 5 && g.NW == 8) ||
                          (g.n == 19 && g.k == 5 && g.NW == 12);
-  const bool use_pair = pair_geom && act_bytes != 2 &&
+  const bool use_pair = pair_geom &&
                         (pair_override >= 0 ? pair_override != 0 : N <= 40960);
   const bool rec = rec_planes && rec_meta;
   if (use_pair) {
@@ -457,8 +458,10 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
     else MNK_PAIR(12, 19, 5, REC, ACTB);                       \
   } while (0)
     if (rec && act_bytes == 1) MNK_PAIR_GEOM(true, 1);
+    else if (rec && act_bytes == 2) MNK_PAIR_GEOM(true, 2);
     else if (rec) MNK_PAIR_GEOM(true, 0);
     else if (act_bytes == 1) MNK_PAIR_GEOM(false, 1);
+    else if (act_bytes == 2) MNK_PAIR_GEOM(false, 2);
     else MNK_PAIR_GEOM(false, 0);
 #undef MNK_PAIR_GEOM
 #undef MNK_PAIR
