@@ -94,20 +94,37 @@ __device__ __forceinline__ bool mnk_plane_wins(const MnkGeom& g, const uint32_t 
   return hit;
 }
 
-// position of the r-th (0-based) set bit of v; r < popcount(v)
+// position of the r-th (0-based) set bit of x; r < popcount(x).
+// A halving search in arithmetic only, as one block of gfx950 assembly: on a wave that is alone on its
+// SIMD every instruction -- VALU, SALU or hazard s_nop -- costs one ~4-cycle issue slot
+// (tools/exp_valu_rate.hip), and the v_cmp -> SGPR -> v_cndmask form the compiler makes of any C++
+// spelling of this costs 8-9 slots per level.  Here a level is five:
+//   t    = popcount(x[pos .. pos+S)) + nr      nr = -(r + 1), negative while bits remain
+//   nr   = umax(nr, t)                         t < 0  <=>  the bit lies above the field: rank -= count
+//   pos |= S & (t >> 31)                       ... and the position moves up
+// The last level looks at one bit: the answer is pos + 1 unless r == 0 and that bit is set.
+#define MNK_SELECT_LEVEL(S)                        \
+  "v_bfe_u32 %[t], %[x], %[pos], " #S "\n\t"       \
+  "v_bcnt_u32_b32 %[t], %[t], %[nr]\n\t"          \
+  "v_max_u32 %[nr], %[nr], %[t]\n\t"              \
+  "v_ashrrev_i32 %[t], 31, %[t]\n\t"              \
+  "v_and_or_b32 %[pos], %[t], " #S ", %[pos]\n\t"
 __device__ __forceinline__ int select_bit32(uint32_t x, int r) {
-  int pos = 0;
-  int c = __popc(x & 0xFFFFu);
-  if (r >= c) { r -= c; x >>= 16; pos = 16; }
-  c = __popc(x & 0xFFu);
-  if (r >= c) { r -= c; x >>= 8; pos += 8; }
-  c = __popc(x & 0xFu);
-  if (r >= c) { r -= c; x >>= 4; pos += 4; }
-  c = __popc(x & 0x3u);
-  if (r >= c) { r -= c; x >>= 2; pos += 2; }
-  if (r >= (int)(x & 1u)) pos += 1;
-  return pos;
+  uint32_t nr = ~(uint32_t)r, pos, t;
+  asm("v_and_b32 %[t], 0xffff, %[x]\n\t"
+      "v_bcnt_u32_b32 %[t], %[t], %[nr]\n\t"
+      "v_max_u32 %[nr], %[nr], %[t]\n\t"
+      "v_ashrrev_i32 %[t], 31, %[t]\n\t"
+      "v_and_b32 %[pos], 16, %[t]\n\t"
+      MNK_SELECT_LEVEL(8) MNK_SELECT_LEVEL(4) MNK_SELECT_LEVEL(2)
+      "v_bfe_u32 %[t], %[x], %[pos], 1\n\t"
+      "v_bitop3_b32 %[t], %[nr], %[t], %[t] bitop3:0x3f\n\t"  // ~(nr & bit): bit 0 clear only if r == 0 and the bit is set
+      "v_and_or_b32 %[pos], %[t], 1, %[pos]"
+      : [pos] "=&v"(pos), [t] "=&v"(t), [nr] "+v"(nr)
+      : [x] "v"(x));
+  return (int)pos;
 }
+#undef MNK_SELECT_LEVEL
 
 template <int NW>
 __device__ __forceinline__ int bs_popcount(const uint32_t (&x)[NW]) {
@@ -117,20 +134,38 @@ __device__ __forceinline__ int bs_popcount(const uint32_t (&x)[NW]) {
   return c;
 }
 
-// bit index of the r-th set bit of the multi-word string; r < popcount
+// bit index of the r-th set bit of the multi-word string (r < popcount), and the string with only
+// that bit set in `hot`.  The word is the last one whose prefix count is <= r: prefix counts never
+// decrease, so the per-word tests are independent of each other.
 template <int NW>
-__device__ __forceinline__ int bs_select(const uint32_t (&x)[NW], int r) {
-  uint32_t word = x[0];
-  int base = 0;
-  bool found = false;
+__device__ __forceinline__ int bs_select_hot(const uint32_t (&x)[NW], int r_, uint32_t (&hot)[NW]) {
+  const uint32_t r = (uint32_t)r_;
+  uint32_t word = x[0], base = 0, before = 0, pre = 0;
+  bool past[NW + 1];
+  past[0] = true;
+  past[NW] = false;
+#pragma unroll
+  for (int w = 1; w < NW; ++w) {
+    pre += (uint32_t)__popc(x[w - 1]);
+    past[w] = r >= pre;
+    word = past[w] ? x[w] : word;
+    base = past[w] ? 32u * w : base;
+    before = past[w] ? pre : before;
+  }
+  const uint32_t pos = (uint32_t)select_bit32(word, (int)(r - before));
+  const uint32_t one = 1u << pos;
 #pragma unroll
   for (int w = 0; w < NW; ++w) {
-    const int c = __popc(x[w]);
-    const bool here = !found && r < c;
-    if (here) { word = x[w]; base = 32 * w; found = true; }
-    if (!found) r -= c;
+    const uint32_t h = (w == 0 || past[w]) ? one : 0u;
+    hot[w] = (w + 1 < NW && past[w + 1]) ? 0u : h;
   }
-  return base + select_bit32(word, r);
+  return (int)(base + pos);
+}
+
+template <int NW>
+__device__ __forceinline__ int bs_select(const uint32_t (&x)[NW], int r) {
+  uint32_t hot[NW];
+  return bs_select_hot<NW>(x, r, hot);
 }
 
 // ---------------------------------------------------------------- Philox4x32-10
@@ -237,12 +272,13 @@ __device__ __forceinline__ int env_pick_legal(const MnkGeom& g, const MnkEnv<NW>
   uint32_t legal[NW];
   env_legal<NW>(g, e, legal);
   const int nl = bs_popcount<NW>(legal);
-  // branch-free: a full board (nl == 0) draws over all C cells; the select below then runs on
-  // an empty string and its result is discarded
+  // a full board (nl == 0, poked states only) draws over all C cells like RandomPolicy's 1e-8 guard
+  // (policy.py:21-24): the select then runs over the valid-cell string, whose r-th set bit is cell r
+#pragma unroll
+  for (int w = 0; w < NW; ++w) legal[w] = nl ? legal[w] : g.valid[w];
   const int r = (int)__umulhi(x, (uint32_t)(nl ? nl : g.C));
   const uint32_t bit = (uint32_t)bs_select<NW>(legal, r);
-  const int cell = (int)(bit - (CN ? bit / (uint32_t)(CN + 1) : mnk_div(bit, g.magic_stride)));
-  return nl ? cell : r;
+  return (int)(bit - (CN ? bit / (uint32_t)(CN + 1) : mnk_div(bit, g.magic_stride)));
 }
 
 struct MnkPly {

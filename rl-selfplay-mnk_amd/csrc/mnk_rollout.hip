@@ -78,31 +78,31 @@ struct RolloutLane {
     quad = 0;
   }
 
-  // uniform legal cell from one u32 (oracle/philox.py pick_legal; selfplay/policy.py:18-29); returns the
-  // bit index of the cell, the action goes to `action`
-  __device__ __forceinline__ uint32_t pick(uint32_t x, int& action) const {
+  // uniform legal cell from one u32 (oracle/philox.py pick_legal; selfplay/policy.py:18-29): the action, and
+  // the cell's bit as a one-hot string
+  __device__ __forceinline__ int pick(uint32_t x, uint32_t (&hot)[NW]) const {
     uint32_t legal[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) legal[w] = ~(cur[w] | oth[w]) & g.valid[w];
     const int nl = bs_popcount<NW>(legal);
+    // full board (poked states only): any cell, like RandomPolicy's 1e-8 guard -- the r-th valid cell is cell r
+#pragma unroll
+    for (int w = 0; w < NW; ++w) legal[w] = nl ? legal[w] : g.valid[w];
     const int r = (int)__umulhi(x, (uint32_t)(nl ? nl : g.C));
-    const uint32_t bit = (uint32_t)bs_select<NW>(legal, r);
-    const uint32_t cell = bit - (CN ? bit / (uint32_t)(CN + 1) : mnk_div(bit, g.magic_stride));
-    action = nl ? (int)cell : r;  // full board (poked states only): any cell, like RandomPolicy's 1e-8 guard
-    // the bit of that cell (the select's result is meaningless on a full board)
-    return nl ? bit : (uint32_t)r + (CN ? (uint32_t)r / (uint32_t)CN : mnk_div((uint32_t)r, g.magic_n));
+    const uint32_t bit = (uint32_t)bs_select_hot<NW>(legal, r, hot);
+    return (int)(bit - (CN ? bit / (uint32_t)(CN + 1) : mnk_div(bit, g.magic_stride)));
   }
 
   // field = position of this ply inside its group of four (= step & 3; a compile-time constant in
   // the unrolled main loop, so the log costs one shift-or per ply and one wide store per four)
   __device__ __forceinline__ void ply(uint32_t x, int field) {
-    int a;
-    const uint32_t bit = pick(x, a);
+    uint32_t hot[NW];
+    const int a = pick(x, hot);
     if (ACT) {
       quad |= (uint64_t)(uint32_t)a << (8 * ACT * field);
       if (field == 3) log_flush();
     }
-    ply_bit(a, bit);
+    ply_hot(a, hot);
   }
 
   // one ply with a known-good action (from an action log the sampler wrote)
@@ -111,16 +111,23 @@ struct RolloutLane {
     ply_bit(a, ua + (CN ? ua / (uint32_t)CN : mnk_div(ua, g.magic_n)));
   }
 
-  // env/torch_vector_mnk_env.py:60-84 for the mover, then env.reset(nonzero(done)) :34-44
   __device__ __forceinline__ void ply_bit(int a, uint32_t bit) {
+    const int wsel = (int)(bit >> 5);
+    const uint32_t one = 1u << (bit & 31u);
+    uint32_t hot[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) hot[w] = (w == wsel) ? one : 0u;
+    ply_hot(a, hot);
+  }
+
+  // env/torch_vector_mnk_env.py:60-84 for the mover, then env.reset(nonzero(done)) :34-44
+  __device__ __forceinline__ void ply_hot(int a, const uint32_t (&hot)[NW]) {
     if (RECORD) {
       store_planes(rp, 0);
       rp += (int64_t)2 * g.W * N;
     }
-    const int wsel = (int)(bit >> 5);
-    const uint32_t one = 1u << (bit & 31u);
 #pragma unroll
-    for (int w = 0; w < NW; ++w) cur[w] |= (w == wsel) ? one : 0u;   // :68
+    for (int w = 0; w < NW; ++w) cur[w] |= hot[w];                    // :68
     ++moves;                                                          // :69
     const uint32_t win = mnk_plane_wins<NW, CN, CK>(g, cur) ? 1u : 0u;  // :71
     const uint32_t done = win | (moves >= (uint32_t)g.C ? 1u : 0u);   // :72-73
@@ -236,7 +243,8 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   if (N == 0 || T == 0) return MNK_OK;
   const int B = 64;
   const dim3 grid((unsigned)((N + B - 1) / B));
-  // two lanes per env only while one lane per env would leave SIMDs without a wave
+  // two lanes per env only while both lanes of every env still fit one wave per SIMD (2N <= 65 536 lanes:
+  // 9x9x5 106 vs 135 us per 256 plies at 32 768 envs, 164 vs 135 at 36 864; tools/exp_pair_threshold.py)
   // (MNK_ROLLOUT_PAIR=0/1 overrides, for A/B timing)
   static int pair_override = -2;
   if (pair_override == -2) {
@@ -247,7 +255,7 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
                          (g.n == 13 && g.k == 5 && g.NW == 6) || (g.n == 15 && g.k == 5 && g.NW == 8) ||
                          (g.n == 19 && g.k == 5 && g.NW == 12);
   const bool use_pair = pair_geom &&
-                        (pair_override >= 0 ? pair_override != 0 : N <= 40960);
+                        (pair_override >= 0 ? pair_override != 0 : N <= 32768);
   const bool rec = rec_planes && rec_meta;
   if (use_pair) {
     mnk_launch_rollout_pair(g, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,
