@@ -29,9 +29,11 @@ struct RolloutLane {
   uint32_t* rm = nullptr;  // rec_meta[t][i]
   uint8_t* ra = nullptr;   // act_log[t / 4][i]
   uint64_t quad = 0;       // the actions of the current group of four plies
-  uint32_t acc_done_draw = 0;    // finished games | draws << 16   (T <= 65535 per launch)
-  uint32_t acc_black_white = 0;  // black wins | white wins << 16
-  uint32_t len_sum = 0;
+  // per-lane statistics, one add each per ply (T <= 65535 per launch): draws = done - wins, black wins =
+  // wins - white wins; the summed length of the finished games needs no counter at all -- every ply adds one
+  // to `moves` and a finished game takes its length out, so it is moves(start) + T - moves(end)
+  uint32_t acc_done = 0, acc_win = 0, acc_white = 0;
+  uint32_t moves_in = 0;
 
   __device__ __forceinline__ RolloutLane(const MnkGeom& g_, int64_t N_, int64_t i, uint64_t* rec_planes,
                                          uint32_t* rec_meta, void* act_log)
@@ -46,7 +48,7 @@ struct RolloutLane {
     plane_load<NW, EXACT>(p1, planes + (int64_t)g.W * N, N, g.W, i);
     const uint32_t mw = meta[i];
     side = mw & 1u;
-    moves = mw >> 1;
+    moves = moves_in = mw >> 1;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
       cur[w] = side ? p1[w] : p0[w];
@@ -85,10 +87,15 @@ struct RolloutLane {
 #pragma unroll
     for (int w = 0; w < NW; ++w) legal[w] = ~(cur[w] | oth[w]) & g.valid[w];
     const int nl = bs_popcount<NW>(legal);
-    // full board (poked states only): any cell, like RandomPolicy's 1e-8 guard -- the r-th valid cell is cell r
+    int n = nl;
+    // full board (poked states only): any cell, like RandomPolicy's 1e-8 guard -- the r-th valid cell is cell r.
+    // A wave-uniform branch that is practically never taken: one compare and one scalar branch per ply.
+    if (__builtin_amdgcn_ballot_w64(nl == 0) != 0) {
 #pragma unroll
-    for (int w = 0; w < NW; ++w) legal[w] = nl ? legal[w] : g.valid[w];
-    const int r = (int)__umulhi(x, (uint32_t)(nl ? nl : g.C));
+      for (int w = 0; w < NW; ++w) legal[w] = nl ? legal[w] : g.valid[w];
+      n = nl ? nl : g.C;
+    }
+    const int r = (int)__umulhi(x, (uint32_t)n);
     const uint32_t bit = (uint32_t)bs_select_hot<NW>(legal, r, hot);
     return (int)(bit - (CN ? bit / (uint32_t)(CN + 1) : mnk_div(bit, g.magic_stride)));
   }
@@ -135,9 +142,9 @@ struct RolloutLane {
       *rm = (uint32_t)a | (win << MNK_REC_REWARD_SHIFT) | (done << MNK_REC_DONE_BIT) | (side << MNK_REC_SIDE_BIT);
       rm += N;
     }
-    acc_done_draw += done + ((done & ~win) << 16);
-    acc_black_white += (win & ~side) + ((win & side) << 16);
-    len_sum += done ? moves : 0u;
+    acc_done += done;
+    acc_win += win;
+    acc_white += win & side;
     // the other side is to move (:82) -- or a fresh game
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
@@ -185,11 +192,12 @@ k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, 
     if (ACT && (T & 3)) L.log_flush();  // T not a multiple of 4: the last word is partly filled
     L.store(planes, meta, i);
     if (stats) {
-      if (L.acc_done_draw & 0xFFFFu) atomicAdd(&lds_stats[0], L.acc_done_draw & 0xFFFFu);
-      if (L.acc_black_white & 0xFFFFu) atomicAdd(&lds_stats[1], L.acc_black_white & 0xFFFFu);
-      if (L.acc_black_white >> 16) atomicAdd(&lds_stats[2], L.acc_black_white >> 16);
-      if (L.acc_done_draw >> 16) atomicAdd(&lds_stats[3], L.acc_done_draw >> 16);
-      if (L.len_sum) atomicAdd(&lds_stats[4], L.len_sum);
+      const uint32_t len_sum = L.moves_in + (uint32_t)T - L.moves;
+      if (L.acc_done) atomicAdd(&lds_stats[0], L.acc_done);
+      if (L.acc_win - L.acc_white) atomicAdd(&lds_stats[1], L.acc_win - L.acc_white);
+      if (L.acc_white) atomicAdd(&lds_stats[2], L.acc_white);
+      if (L.acc_done - L.acc_win) atomicAdd(&lds_stats[3], L.acc_done - L.acc_win);
+      if (len_sum) atomicAdd(&lds_stats[4], len_sum);
     }
   }
   __syncthreads();
