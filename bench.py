@@ -72,11 +72,12 @@ def parse():
     return ap.parse_args()
 
 
-def record_bytes(words):
+def record_bytes(rows):
     """Algorithmic HBM bytes of one env-step inside the fused rollout:
-    the packed record R = 16*W + 4 that is written for every ply; the state itself lives in
-    registers for the whole launch (its load/store is amortised over the chunk)."""
-    return 16 * words + 4
+    the packed record R = 8 * rows + 4 that is written for every ply (rows = mnk_record_words: the 32-bit
+    words of both planes, interleaved, no padding); the state itself lives in registers for the whole launch
+    (its load/store is amortised over the chunk)."""
+    return 8 * rows + 4
 
 
 def state_bytes(words):
@@ -452,10 +453,11 @@ def main():
     words = env.words
     # roofline of the dominant kernel (mnk_rollout_random): algorithmic bytes per launch / avg launch time
     plies_per_launch = chunk
-    alg_bytes = nenv * (plies_per_launch * record_bytes(words) + 2 * state_bytes(words))
+    rows = mnk_hip.record_words(m, n)
+    alg_bytes = nenv * (plies_per_launch * record_bytes(rows) + 2 * state_bytes(words))
     launch_s = dev_ms * 1e-3 / launches
     achieved = alg_bytes / launch_s / 1e9
-    survey_b_roll = state_bytes(words) + 8 * words + 4 + record_bytes(words)  # 92 B at 9x9
+    survey_b_roll = state_bytes(words) + 8 * words + 4 + state_bytes(words)  # 92 B at 9x9
     out = {
         "metric": f"env-steps/sec {m}x{n}x{k}, {nenv} parallel envs/GPU, random-policy rollout",
         "value": value,
@@ -492,7 +494,7 @@ def main():
             "kernel": "k_rollout_random",
             "launches": launches,
             "avg_launch_us": launch_s * 1e6,
-            "alg_bytes_per_env_step": record_bytes(words) + 2 * state_bytes(words) / plies_per_launch,
+            "alg_bytes_per_env_step": record_bytes(rows) + 2 * state_bytes(words) / plies_per_launch,
             "achieved_at_survey_B_roll": survey_b_roll * nenv * plies_per_launch / launch_s / 1e9,
         },
     }

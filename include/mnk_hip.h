@@ -28,6 +28,12 @@
  *                          W-word little-endian bit string; column n of each row is a
  *                          guard column that is always 0;  W = mnk_state_words(m, n)
  *   meta    u32[N]         bit 0 = side to move (0 black, 1 white), bits 1..31 = move count
+ *
+ * Rollout record of one position (what mnk_rollout_random / mnk_replay_actions write per ply):
+ *   rows    u64[R][N]      row w = (32-bit word w of the black plane) | (word w of the white plane) << 32,
+ *                          same bit numbering as above; R = mnk_record_words(m, n) = ceil(m*(n+1)/32).
+ *                          No padding at any board size: 24 B at 9x9 where two state planes take 32 B --
+ *                          the rollout is bound by these stores.
  */
 #ifndef MNK_HIP_H
 #define MNK_HIP_H
@@ -39,7 +45,7 @@
 extern "C" {
 #endif
 
-#define MNK_ABI_VERSION 1
+#define MNK_ABI_VERSION 2
 
 /* status codes (host-side argument checks) */
 #define MNK_OK 0
@@ -81,6 +87,8 @@ extern "C" {
 int mnk_abi_version(void);
 /* W = ceil(m*(n+1)/64), or 0 when the geometry is unsupported */
 int mnk_state_words(int m, int n);
+/* R = ceil(m*(n+1)/32), rows of one rollout record; 0 when the geometry is unsupported */
+int mnk_record_words(int m, int n);
 /* 1 when 1 <= k <= min(m,n), n <= 61 and W <= 8 (boards up to 22x22) */
 int mnk_geometry_supported(int m, int n, int k);
 const char* mnk_last_launch_error(void);
@@ -174,7 +182,8 @@ int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m,
 
 /* ---- the random-policy rollout of BASELINE.json (RandomPolicy.act -> env.step -> env.reset(done)),
  * T plies per env in one launch with the state held in registers.
- * rec_planes u64[T][2][W][N]: absolute planes BEFORE each ply; rec_meta u32[T][N]: MNK_REC_* word;
+ * rec_planes u64[T][R][N]: the position BEFORE each ply (record rows, see the top of this file);
+ * rec_meta u32[T][N]: MNK_REC_* word;
  * stats (optional) int64[MNK_STATS_REPLICAS][MNK_STATS_STRIDE] += {episodes finished, black wins,
  * white wins, draws, sum of episode lengths} spread over the replicas (sum the rows to read a counter).
  * rec_planes / rec_meta may be NULL together (state-only rollout); act_log may be NULL. */
@@ -185,7 +194,7 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
 
 /* The multi-GPU exchange format.  A shard's rollout is a pure function of its chunk-start state and
  * its actions, so the action log, optionally written by mnk_rollout_random, is what ranks all-gather
- * (1-2 B per env-step instead of the 36 B packed record or the reference's 750 B RolloutBuffer row).
+ * (1-2 B per env-step instead of the 28 B packed record or the reference's 750 B RolloutBuffer row).
  * Layout: four plies per word, act_log u32[ceil(T/4)][N] (act_bytes 1: one byte per action, boards with
  * <= 256 cells) or u64[ceil(T/4)][N] (act_bytes 2: 16 bits per action); the action of ply 4q+j is field j
  * (little-endian) of word [q][i]; fields past T are 0.  With a log, step0 must be a multiple of 4 (every

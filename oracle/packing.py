@@ -68,3 +68,34 @@ def valid_cell_words(m: int, n: int) -> np.ndarray:
     for b in cell_bit_index(m, n):
         out[b >> 6] |= np.uint64(1) << np.uint64(b & 63)
     return out
+
+
+def record_words(m: int, n: int) -> int:
+    """Rows of one rollout record: ceil(m*(n+1)/32) (include/mnk_hip.h, "Rollout record")."""
+    return (m * (n + 1) + 31) // 32
+
+
+def record_rows(planes: np.ndarray, m: int, n: int) -> np.ndarray:
+    """State-layout planes u64[..., 2, W, N] -> record rows u64[..., R, N]: row w = 32-bit word w of the
+    black plane | word w of the white plane << 32."""
+    planes = np.ascontiguousarray(planes, dtype=np.uint64)
+    lead, (two, w, nenv) = planes.shape[:-3], planes.shape[-3:]
+    assert two == 2 and w == words_per_plane(m, n)
+    r = record_words(m, n)
+    lo = planes & np.uint64(0xFFFFFFFF)
+    hi = planes >> np.uint64(32)
+    halves = np.stack([lo, hi], axis=-2).reshape(lead + (2, 2 * w, nenv))[..., :r, :]  # [.., plane, word32, N]
+    return halves[..., 0, :, :] | (halves[..., 1, :, :] << np.uint64(32))
+
+
+def planes_from_record_rows(rows: np.ndarray, m: int, n: int) -> np.ndarray:
+    """Inverse of ``record_rows``: u64[..., R, N] -> u64[..., 2, W, N]."""
+    rows = np.ascontiguousarray(rows, dtype=np.uint64)
+    lead, (r, nenv) = rows.shape[:-2], rows.shape[-2:]
+    w = words_per_plane(m, n)
+    assert r == record_words(m, n)
+    halves = np.zeros(lead + (2, 2 * w, nenv), dtype=np.uint64)
+    halves[..., 0, :r, :] = rows & np.uint64(0xFFFFFFFF)
+    halves[..., 1, :r, :] = rows >> np.uint64(32)
+    pairs = halves.reshape(lead + (2, w, 2, nenv))
+    return pairs[..., 0, :] | (pairs[..., 1, :] << np.uint64(32))

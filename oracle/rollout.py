@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import philox
-from .packing import pack_boards
+from .packing import pack_boards, record_rows, record_words
 
 REC_ACTION_MASK = 0xFFFF
 REC_REWARD_SHIFT = 16  # i8 in bits 16..23
@@ -39,8 +39,8 @@ def encode_record(action, reward, done, side) -> np.ndarray:
 def random_rollout(env, seed: int, step0: int, steps: int, env_id0: int = 0):
     """Run ``steps`` random plies on every env of ``env`` (an OracleVectorEnv).
 
-    Returns (rec_planes u64[T,2,W,N], rec_meta u32[T,N], stats i64[5]) where the
-    planes are the absolute boards *before* the ply and stats =
+    Returns (rec_planes u64[T,R,N], rec_meta u32[T,N], stats i64[5]) where the
+    planes are the absolute boards *before* the ply as record rows (``packing.record_rows``) and stats =
     [episodes finished, black wins, white wins, draws, sum of finished-episode lengths].
     """
     m, n = env.m, env.n
@@ -51,7 +51,7 @@ def random_rollout(env, seed: int, step0: int, steps: int, env_id0: int = 0):
     for t in range(steps):
         before = env.observe()
         side = env.current_player.numpy().copy()
-        rec_planes.append(pack_boards(before["observation"].numpy(), m, n))
+        rec_planes.append(record_rows(pack_boards(before["observation"].numpy(), m, n), m, n))
         x = philox.rand_u32(seed, ids, step0 + t, philox.STREAM_MOVE)
         act = philox.pick_legal(before["action_mask"].numpy(), x)
         _, rew, done = env.step(torch.from_numpy(act))
@@ -67,8 +67,7 @@ def random_rollout(env, seed: int, step0: int, steps: int, env_id0: int = 0):
             stats[3] += int((~won).sum())
             stats[4] += int(lengths.sum())
             env.reset(torch.from_numpy(np.nonzero(done_np)[0]))
-    w = rec_planes[0].shape[1] if rec_planes else 0
-    planes = np.stack(rec_planes) if rec_planes else np.zeros((0, 2, w, nenv), np.uint64)
+    planes = np.stack(rec_planes) if rec_planes else np.zeros((0, record_words(m, n), nenv), np.uint64)
     meta = np.stack(rec_meta) if rec_meta else np.zeros((0, nenv), np.uint32)
     return planes, meta, stats
 
@@ -76,12 +75,12 @@ def random_rollout(env, seed: int, step0: int, steps: int, env_id0: int = 0):
 def replay_actions(env, actions):
     """Replays an action log on ``env`` (an OracleVectorEnv in its chunk-start state): the records the
     fused rollout would have written for those actions -- what ``mnk_replay_actions`` must rebuild.
-    actions: int array [T, N].  Returns (rec_planes u64[T,2,W,N], rec_meta u32[T,N])."""
+    actions: int array [T, N].  Returns (rec_planes u64[T,R,N], rec_meta u32[T,N])."""
     m, n = env.m, env.n
     rec_planes, rec_meta = [], []
     for act in np.asarray(actions, dtype=np.int64):
         side = env.current_player.numpy().copy()
-        rec_planes.append(pack_boards(env.boards.numpy(), m, n))
+        rec_planes.append(record_rows(pack_boards(env.boards.numpy(), m, n), m, n))
         _, rew, done = env.step(torch.from_numpy(act))
         done_np = done.numpy()
         rec_meta.append(encode_record(act, rew.numpy().astype(np.int64), done_np, side))

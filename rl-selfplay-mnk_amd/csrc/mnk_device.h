@@ -235,6 +235,30 @@ __device__ __forceinline__ void plane_store(const uint32_t (&x)[NW], uint64_t* p
   }
 }
 
+// ---------------------------------------------------------------- rollout records
+// One recorded position is NW u64 rows of stride N: row w = black word w | white word w << 32 (the
+// 32-bit words of the two planes, interleaved).  No padding at any board size -- 9x9 takes 3 rows =
+// 24 B where the state layout's two u64 planes take 32 -- and the rollout is bound by exactly these
+// stores.  nw = the board's word count (MnkGeom::NW), used when NW is only an upper bound.
+template <int NW, bool EXACT = false>
+__device__ __forceinline__ void rec_store(const uint32_t (&p0)[NW], const uint32_t (&p1)[NW], uint64_t* rows, int64_t N,
+                                          int nw, int64_t i) {
+#pragma unroll
+  for (int w = 0; w < NW; ++w)
+    if (EXACT || w < nw) rows[(int64_t)w * N + i] = (uint64_t)p0[w] | ((uint64_t)p1[w] << 32);
+}
+
+template <int NW, bool EXACT = false>
+__device__ __forceinline__ void rec_load(uint32_t (&p0)[NW], uint32_t (&p1)[NW], const uint64_t* rows, int64_t N, int nw,
+                                         int64_t i) {
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const uint64_t v = (EXACT || w < nw) ? rows[(int64_t)w * N + i] : 0ull;
+    p0[w] = (uint32_t)v;
+    p1[w] = (uint32_t)(v >> 32);
+  }
+}
+
 template <int NW, bool EXACT = false>
 __device__ __forceinline__ void env_load(MnkEnv<NW>& e, const uint64_t* planes, const uint32_t* meta, int64_t N,
                                          int W, int64_t i) {

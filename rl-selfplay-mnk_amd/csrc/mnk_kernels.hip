@@ -498,9 +498,7 @@ k_unpack_records(MnkGeom g, const uint64_t* rec_planes, const uint32_t* rec_meta
     if (dones) dones[t * N + i] = (uint8_t)((mw >> MNK_REC_DONE_BIT) & 1u);
     if (emit) {
       uint32_t p0[NW], p1[NW];
-      const uint64_t* rp = rec_planes + t * 2 * g.W * N;
-      plane_load<NW>(p0, rp, N, g.W, i);
-      plane_load<NW>(p1, rp + (int64_t)g.W * N, N, g.W, i);
+      rec_load<NW>(p0, p1, rec_planes + t * g.NW * N, N, g.NW, i);
       const bool flip = ((mw >> MNK_REC_SIDE_BIT) & 1u) != 0;  // the mover sees itself in channel 0
       if (flip) mnk_stage_put<NW>(st, g, B, tid, p1, p0, false);
       else mnk_stage_put<NW>(st, g, B, tid, p0, p1, false);
@@ -607,6 +605,12 @@ k_gae(const float* rewards, const float* values, const uint8_t* dones, const flo
 extern "C" {
 
 int mnk_abi_version(void) { return MNK_ABI_VERSION; }
+
+int mnk_record_words(int m, int n) {
+  MnkGeom g;
+  if (mnk_check_geom(m, n, 1, &g) != MNK_OK) return 0;
+  return g.NW;
+}
 
 int mnk_state_words(int m, int n) {
   if (m < 1 || n < 1 || n > 61) return 0;

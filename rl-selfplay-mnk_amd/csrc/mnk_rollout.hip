@@ -5,7 +5,7 @@
 
 // ------------------------------------------------------------------ fused random rollout
 // T plies per env in one launch; state lives in registers, HBM sees one load and one
-// store of the state per launch plus the 36-byte (9x9) record of every ply.
+// store of the state per launch plus the 28-byte (9x9) record of every ply.
 // The loop is laid out for a wave that is alone on its SIMD (65 536 envs = 1024 waves =
 // one per SIMD): no divergent branch, per-lane bookkeeping instead of per-ply ballots
 // (scalar round trips), four plies per Philox block with the word picked at compile time.
@@ -25,7 +25,7 @@ struct RolloutLane {
   uint32_t side, moves;
   int64_t N;
   // this lane's cursors into the record arrays; they advance by one ply's stride after every ply
-  uint64_t* rp = nullptr;  // rec_planes[t][0][0][i]
+  uint64_t* rp = nullptr;  // rec_planes[t][0][i]
   uint32_t* rm = nullptr;  // rec_meta[t][i]
   uint8_t* ra = nullptr;   // act_log[t / 4][i]
   uint64_t quad = 0;       // the actions of the current group of four plies
@@ -66,6 +66,18 @@ struct RolloutLane {
     }
     plane_store<NW, EXACT>(p0, dst, N, g.W, i);
     plane_store<NW, EXACT>(p1, dst + (int64_t)g.W * N, N, g.W, i);
+  }
+
+  // the position before a ply as one record (rec_store's row layout), cursor moves on to the next ply
+  __device__ __forceinline__ void store_record() {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      if (EXACT || w < g.NW) {
+        const uint32_t black = side ? oth[w] : cur[w], white = side ? cur[w] : oth[w];
+        rp[(int64_t)w * N] = (uint64_t)black | ((uint64_t)white << 32);
+      }
+    }
+    rp += (int64_t)g.NW * N;
   }
 
   __device__ __forceinline__ void store(uint64_t* planes, uint32_t* meta, int64_t i) const {
@@ -129,10 +141,7 @@ struct RolloutLane {
 
   // env/torch_vector_mnk_env.py:60-84 for the mover, then env.reset(nonzero(done)) :34-44
   __device__ __forceinline__ void ply_hot(int a, const uint32_t (&hot)[NW]) {
-    if (RECORD) {
-      store_planes(rp, 0);
-      rp += (int64_t)2 * g.W * N;
-    }
+    if (RECORD) store_record();
 #pragma unroll
     for (int w = 0; w < NW; ++w) cur[w] |= hot[w];                    // :68
     ++moves;                                                          // :69

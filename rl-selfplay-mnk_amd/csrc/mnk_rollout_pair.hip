@@ -75,7 +75,7 @@ struct PairLane {
   MnkEnv<NW> e;
   int64_t N;
   uint32_t role;      // 0 / 1 within the pair
-  uint64_t* rp = nullptr;  // rec_planes[t][role][0][env]
+  uint32_t* rp = nullptr;  // half `role` of rec_planes[t][0][env]: lane 0 writes the black words, lane 1 the white
   uint32_t* rm = nullptr;  // rec_meta[t][env]
   uint8_t* ra = nullptr;   // act_log[t / 4][env]
   uint64_t quad = 0;       // four actions, 8 or 16 bits each (ACT = 1 / 2)
@@ -84,7 +84,7 @@ struct PairLane {
   __device__ __forceinline__ PairLane(const MnkGeom& g_, int64_t N_, int64_t env, uint32_t role_,
                                       uint64_t* rec_planes, uint32_t* rec_meta, void* act_log)
       : g(g_), N(N_), role(role_) {
-    if (RECORD) { rp = rec_planes + (int64_t)role * g.W * N + env; rm = rec_meta + env; }
+    if (RECORD) { rp = (uint32_t*)(rec_planes + env) + role; rm = rec_meta + env; }
     if (ACT) ra = (uint8_t*)act_log + env * 4 * ACT;
   }
 
@@ -94,12 +94,10 @@ struct PairLane {
       quad |= (uint64_t)(uint32_t)a << (8 * ACT * field);
       if (field == 3) flush_log();
     }
-    if (RECORD) {  // lane `role` writes plane `role` of the board before the ply
-      uint32_t mine_plane[NW];
+    if (RECORD) {  // lane `role` writes its half of every row of the board before the ply: one 256-byte store per wave
 #pragma unroll
-      for (int w = 0; w < NW; ++w) mine_plane[w] = role ? e.p[1][w] : e.p[0][w];
-      plane_store<NW, true>(mine_plane, rp, N, g.W, 0);
-      rp += (int64_t)2 * g.W * N;
+      for (int w = 0; w < NW; ++w) rp[(int64_t)w * 2 * N] = role ? e.p[1][w] : e.p[0][w];
+      rp += (int64_t)NW * 2 * N;
     }
     const uint32_t side = e.meta & 1u;
     const uint32_t bit = (uint32_t)a + (uint32_t)a / (uint32_t)CN;

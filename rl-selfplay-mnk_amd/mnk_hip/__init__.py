@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmnk_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 MNK_OK = 0
 ERR_NONE, ERR_ACTION_RANGE, ERR_ILLEGAL_MOVE = 0, 1, 2
@@ -29,6 +29,7 @@ _vp, _i, _i64, _u64, _u32, _f = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, 
 SIGNATURES = {
     "mnk_abi_version": [],
     "mnk_state_words": [_i, _i],
+    "mnk_record_words": [_i, _i],
     "mnk_geometry_supported": [_i, _i, _i],
     "mnk_last_launch_error": [],
     "mnk_reset_all": [_vp, _vp, _i64, _i, _vp],
@@ -116,6 +117,10 @@ def call(name, *args):
 
 def state_words(m, n):
     return load().mnk_state_words(m, n)
+
+
+def record_words(m: int, n: int) -> int:
+    return load().mnk_record_words(m, n)
 
 
 def geometry_supported(m, n, k):

@@ -7,7 +7,8 @@ SURVEY.md Appendix A -- ``RandomPolicy.act`` (``src/selfplay/policy.py:18-29``) 
 every env run inside ``mnk_rollout_random`` with the state in registers; what reaches
 HBM is the packed record of each ply:
 
-    planes  u64[T][2][W][N]   the board *before* the ply (absolute planes)
+    planes  u64[T][R][N]      the board *before* the ply: row w = black word w | white word w << 32
+                              (32-bit words of the absolute planes; R = ceil(m*(n+1)/32), no padding)
     meta    u32[T][N]         action | reward << 16 | done << 24 | mover side << 25
 
 Envs are independent, so a node shards them by contiguous blocks: rank r owns global
@@ -15,7 +16,7 @@ env ids [r*N, (r+1)*N) and the Philox key uses the global id, which makes the re
 independent of the number of GPUs.  There is one exchange step, an all-gather over the
 process group (RCCL over xGMI when the backend is ``nccl``), in one of two formats:
 
-  * ``gather_records``      the packed records themselves (36 B per env-step at 9x9);
+  * ``gather_records``      the packed records themselves (28 B per env-step at 9x9);
   * ``gather_action_logs``  the chunk-start state plus the action log (1-2 B per env-step):
                             a rollout is a pure function of those, and ``replay_shard`` rebuilds
                             any shard's full records bit-identically on the receiving GPU.
@@ -30,7 +31,7 @@ import mnk_hip
 
 @dataclass
 class RolloutRecords:
-    planes: torch.Tensor  # int64 (u64 bits) [T, 2, W, N]
+    planes: torch.Tensor  # int64 (u64 bits) [T, R, N], R = mnk_hip.record_words(m, n)
     meta: torch.Tensor    # int32 (u32 bits) [T, N]
     # only when the action log is on (alloc(..., log_actions=True)); all three are views into `msg`
     act: Optional[torch.Tensor] = None      # action log, 4 plies per word: int32 / int64 [ceil(T/4), N]
@@ -78,7 +79,8 @@ class RandomRollout:
     def alloc(self, steps: int, log_actions: bool = False) -> RolloutRecords:
         env = self.env
         rec = RolloutRecords(
-            planes=torch.empty((steps, 2, env.words, env.num_envs), dtype=torch.int64, device=env._dev),
+            planes=torch.empty((steps, mnk_hip.record_words(env.m, env.n), env.num_envs), dtype=torch.int64,
+                               device=env._dev),
             meta=torch.empty((steps, env.num_envs), dtype=torch.int32, device=env._dev),
         )
         if log_actions:
@@ -176,7 +178,8 @@ def gather_action_logs(rec: RolloutRecords, group=None, out: Optional[GatheredLo
 
     assert rec.msg is not None, "run the rollout with alloc(..., log_actions=True)"
     world = dist.get_world_size(group)
-    t, two, w, n = rec.planes.shape
+    t, n = rec.meta.shape
+    w = rec.planes0.shape[1]  # the chunk-start state travels in the state layout [2, W, N]
     num_actions = 256 if rec.act.dtype == torch.int32 else 65536
     if out is None:
         out = GatheredLogs.empty(world, w, n, t, num_actions, rec.msg.device)
@@ -195,9 +198,8 @@ def replay_shard(logs: GatheredLogs, shard: int, m: int, n: int, k: int, err: Op
     dev = act.device
     planes = logs.planes0[shard].clone()
     meta = logs.meta0[shard].clone()
-    words = planes.shape[1]
     if out is None:
-        out = RolloutRecords(planes=torch.empty((t, 2, words, nenv), dtype=torch.int64, device=dev),
+        out = RolloutRecords(planes=torch.empty((t, mnk_hip.record_words(m, n), nenv), dtype=torch.int64, device=dev),
                              meta=torch.empty((t, nenv), dtype=torch.int32, device=dev))
     if err is None:
         err = torch.zeros(2, dtype=torch.int32, device=dev)
@@ -210,7 +212,7 @@ def replay_shard(logs: GatheredLogs, shard: int, m: int, n: int, k: int, err: Op
 
 def gather_records(rec: RolloutRecords, group=None) -> RolloutRecords:
     """All-gather of the packed records over the env axis: every rank ends up with
-    [T, 2, W, world*N] / [T, world*N], rank r's envs at columns [r*N, (r+1)*N).
+    [T, R, world*N] / [T, world*N], rank r's envs at columns [r*N, (r+1)*N).
 
     Uses ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI on the GPUs, ``gloo`` in
     the CPU tests).  The collective gathers rank-major buffers; the permute back to the
@@ -221,13 +223,13 @@ def gather_records(rec: RolloutRecords, group=None) -> RolloutRecords:
     world = dist.get_world_size(group)
     if world == 1:
         return rec
-    t, two, w, n = rec.planes.shape
-    planes_all = torch.empty((world, t, two, w, n), dtype=rec.planes.dtype, device=rec.planes.device)
+    t, rows, n = rec.planes.shape
+    planes_all = torch.empty((world, t, rows, n), dtype=rec.planes.dtype, device=rec.planes.device)
     meta_all = torch.empty((world, t, n), dtype=rec.meta.dtype, device=rec.meta.device)
     # flat views: the concatenated form every backend accepts (gloo rejects the stacked shape)
     dist.all_gather_into_tensor(planes_all.view(-1), rec.planes.contiguous().view(-1), group=group)
     dist.all_gather_into_tensor(meta_all.view(-1), rec.meta.contiguous().view(-1), group=group)
-    planes = planes_all.permute(1, 2, 3, 0, 4).reshape(t, two, w, world * n)
+    planes = planes_all.permute(1, 2, 0, 3).reshape(t, rows, world * n)
     meta = meta_all.permute(1, 0, 2).reshape(t, world * n)
     return RolloutRecords(planes=planes.contiguous(), meta=meta.contiguous())
 

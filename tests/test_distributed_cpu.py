@@ -37,7 +37,7 @@ def _worker(rank, world, port, m, n, k, nenv, steps, seed, out_dir):
         planes, meta, stats = random_rollout(env, seed=seed, step0=0, steps=steps, env_id0=rank * nenv)
         rec = RolloutRecords(planes=torch.from_numpy(planes.view(np.int64)), meta=torch.from_numpy(meta.view(np.int32)))
         full = gather_records(rec)
-        assert full.planes.shape == (steps, 2, planes.shape[2], world * nenv)
+        assert full.planes.shape == (steps, planes.shape[1], world * nenv)
         assert full.meta.shape == (steps, world * nenv)
         # the compact exchange format: chunk-start state + action log
         from selfplay.random_rollout import gather_action_logs
@@ -46,15 +46,17 @@ def _worker(rank, world, port, m, n, k, nenv, steps, seed, out_dir):
         pad = np.zeros(((-steps) % 4, nenv), dtype=np.int64)
         quads = np.concatenate([acts, pad]).reshape(-1, 4, nenv)
         from selfplay.random_rollout import _msg_views, _msg_words
-        words = planes.shape[2]
+        from oracle.packing import words_per_plane
+        words = words_per_plane(m, n)
         rec.msg = torch.zeros(_msg_words(words, nenv, steps, m * n), dtype=torch.int64)
         rec.planes0, rec.act, rec.meta0 = _msg_views(rec.msg, words, nenv, steps, m * n)
         rec.act.copy_(torch.from_numpy((quads[:, 0] | quads[:, 1] << 8 | quads[:, 2] << 16 | quads[:, 3] << 24).astype(np.int32)))
-        rec.planes0.copy_(rec.planes[0])
+        rec.planes0.zero_()  # state layout [2, W, N]; every env starts from an empty board
+        assert not rec.planes[0].any()
         rec.meta0.zero_()  # every env starts from reset
         logs = gather_action_logs(rec)
         assert logs.act.shape == (world, (steps + 3) // 4, nenv) and logs.planes0.shape[0] == world and logs.steps == steps
-        assert torch.equal(logs.act[rank], rec.act) and torch.equal(logs.planes0[rank], rec.planes[0])
+        assert torch.equal(logs.act[rank], rec.act) and torch.equal(logs.planes0[rank], rec.planes0)
         for r in range(world):
             assert torch.equal(unpack_action_log(logs.act[r], steps),
                                (full.meta[:, r * nenv:(r + 1) * nenv] & 0xFFFF).to(torch.int64))
@@ -89,7 +91,7 @@ def test_gather_is_identity_for_one_rank(tmp_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
     dist.init_process_group("gloo", rank=0, world_size=1)
     try:
-        rec = RolloutRecords(planes=torch.zeros((3, 2, 2, 8), dtype=torch.int64), meta=torch.ones((3, 8), dtype=torch.int32))
+        rec = RolloutRecords(planes=torch.zeros((3, 3, 8), dtype=torch.int64), meta=torch.ones((3, 8), dtype=torch.int32))
         assert gather_records(rec) is rec
     finally:
         dist.destroy_process_group()

@@ -6,7 +6,7 @@ import torch
 
 from oracle import philox
 from oracle.env_torch import OracleVectorEnv
-from oracle.packing import pack_boards
+from oracle.packing import pack_boards, record_rows
 from oracle.rollout import random_rollout
 from oracle.rollout import replay_actions as oracle_replay
 from replay import golden_files, play_scenario, replay_env_log
@@ -187,7 +187,7 @@ def test_rollout_is_independent_of_sharding(hip):
     m, n, k = 9, 9, 5
     whole = hip.Rollout(hip.Env(m, n, k, 192, device=DEV), seed=3).run(70)
     parts = [hip.Rollout(hip.Env(m, n, k, 96, device=DEV), seed=3, env_id0=96 * r).run(70) for r in (0, 1)]
-    assert torch.equal(whole.planes, torch.cat([p.planes for p in parts], dim=3))
+    assert torch.equal(whole.planes, torch.cat([p.planes for p in parts], dim=2))
     assert torch.equal(whole.meta, torch.cat([p.meta for p in parts], dim=1))
 
 
@@ -200,11 +200,12 @@ def test_full_size_rollout_properties(hip):
     env = hip.Env(m, n, k, nenv, device=DEV)
     roll = hip.Rollout(env, seed=1)
     rec = roll.run(steps)
-    planes = rec.planes  # [T,2,W,N] int64
+    rows = rec.planes  # [T,R,N] int64: black word | white word << 32
+    planes = torch.stack([rows & 0xFFFFFFFF, (rows >> 32) & 0xFFFFFFFF], dim=1)  # [T,2,R,N] 32-bit words
     act = rec.actions()
     bit = act + act // n
-    word, sh = bit >> 6, bit & 63
-    occ = planes[:, 0] | planes[:, 1]  # [T,W,N]
+    word, sh = bit >> 5, bit & 31
+    occ = planes[:, 0] | planes[:, 1]  # [T,R,N]
     occ_at = torch.gather(occ, 1, word.unsqueeze(1)).squeeze(1)
     assert not bool(((occ_at >> sh) & 1).any()), "an occupied cell was played"
     side = rec.sides()
@@ -216,6 +217,7 @@ def test_full_size_rollout_properties(hip):
             stone[:, p, w] = torch.where((side[:-1] == p) & (word[:-1] == w), one, torch.zeros_like(one))
     expect = torch.where(done[:-1].unsqueeze(1).unsqueeze(1), torch.zeros_like(stone), planes[:-1] | stone)
     assert torch.equal(planes[1:], expect)
+    del rows
     del planes, occ, stone, expect, one
     roll.run(640, record=False)  # a longer window so games cut off at its end do not bias the mean
     episodes, black, white, draws, length = roll.stats.tolist()
@@ -246,7 +248,9 @@ def test_action_log_replay_rebuilds_the_records(hip, m, n, k, nenv, steps):
         assert rec.act.shape == ((steps + 3) // 4, nenv)
         actions = unpack_action_log(rec.act, steps)
         assert torch.equal(actions, rec.actions())
-        assert torch.equal(rec.planes0, rec.planes[0])  # the chunk-start state travels with the log
+        # the chunk-start state travels with the log (state layout; the first record is the same position)
+        assert np.array_equal(record_rows(rec.planes0.cpu().numpy().view(np.uint64), m, n),
+                              rec.planes[0].cpu().numpy().view(np.uint64))
         logs = GatheredLogs.empty(1, env.words, nenv, steps, m * n, DEV)
         logs.msg.copy_(rec.msg.unsqueeze(0))  # what a one-rank all-gather delivers
         again = replay_shard(logs, 0, m, n, k)

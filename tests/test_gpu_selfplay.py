@@ -6,7 +6,7 @@ import torch
 
 from oracle import philox
 from oracle.env_torch import OracleVectorEnv
-from oracle.packing import pack_boards, pack_cells, unpack_boards
+from oracle.packing import pack_boards, pack_cells, planes_from_record_rows, unpack_boards
 from oracle.policies import (FixedCellPolicy, HighestLegalPolicy, LowestLegalPolicy, MaskHashPolicy,
                              PhiloxOpponent)
 from oracle.rollout import gae as oracle_gae
@@ -276,7 +276,7 @@ def test_unpack_records_matches_numpy(hip, m, n, k, nenv, steps):
     meta = rec.meta.cpu().numpy().view(np.uint32)
     side = (meta >> 25) & 1
     for t in range(steps):
-        dense = unpack_boards(planes[t], m, n)
+        dense = unpack_boards(planes_from_record_rows(planes[t], m, n), m, n)
         flip = side[t] == 1
         dense[flip] = dense[flip][:, ::-1]
         assert np.array_equal(buf["observations"][t].cpu().numpy(), dense)
