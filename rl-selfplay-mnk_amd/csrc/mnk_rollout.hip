@@ -74,7 +74,7 @@ struct RolloutLane {
     for (int w = 0; w < NW; ++w) {
       if (EXACT || w < g.NW) {
         const uint32_t black = side ? oth[w] : cur[w], white = side ? cur[w] : oth[w];
-        rp[(int64_t)w * N] = (uint64_t)black | ((uint64_t)white << 32);
+        __builtin_nontemporal_store((uint64_t)black | ((uint64_t)white << 32), rp + (int64_t)w * N);
       }
     }
     rp += (int64_t)g.NW * N;
@@ -148,7 +148,7 @@ struct RolloutLane {
     const uint32_t win = mnk_plane_wins<NW, CN, CK>(g, cur) ? 1u : 0u;  // :71
     const uint32_t done = win | (moves >= (uint32_t)g.C ? 1u : 0u);   // :72-73
     if (RECORD) {
-      *rm = (uint32_t)a | (win << MNK_REC_REWARD_SHIFT) | (done << MNK_REC_DONE_BIT) | (side << MNK_REC_SIDE_BIT);
+      __builtin_nontemporal_store((uint32_t)a | (win << MNK_REC_REWARD_SHIFT) | (done << MNK_REC_DONE_BIT) | (side << MNK_REC_SIDE_BIT), rm);
       rm += N;
     }
     acc_done += done;
