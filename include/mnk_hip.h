@@ -30,8 +30,10 @@
  *   meta    u32[N]         bit 0 = side to move (0 black, 1 white), bits 1..31 = move count
  *
  * Rollout record of one position (what mnk_rollout_random / mnk_replay_actions write per ply):
- *   rows    u64[R][N]      row w = (32-bit word w of the black plane) | (word w of the white plane) << 32,
+ *   rows    u64[R][N]      row w = (32-bit word w of the MOVER's plane) | (word w of the other side's plane) << 32,
  *                          same bit numbering as above; R = mnk_record_words(m, n) = ceil(m*(n+1)/32).
+ *                          Which colour the mover is says MNK_REC_SIDE_BIT of the ply's meta word (0 = black).
+ *                          This is the view the policy sees (channel 0 = own stones, wrapper.py:99-106).
  *                          No padding at any board size: 24 B at 9x9 where two state planes take 32 B --
  *                          the rollout is bound by these stores.
  */

@@ -75,12 +75,16 @@ def record_words(m: int, n: int) -> int:
     return (m * (n + 1) + 31) // 32
 
 
-def record_rows(planes: np.ndarray, m: int, n: int) -> np.ndarray:
+def record_rows(planes: np.ndarray, m: int, n: int, side=None) -> np.ndarray:
     """State-layout planes u64[..., 2, W, N] -> record rows u64[..., R, N]: row w = 32-bit word w of the
-    black plane | word w of the white plane << 32."""
+    first plane | word w of the second plane << 32.  ``side`` (int array [..., N], 0 black / 1 white to move):
+    the rollout records the MOVER's plane first, so white-to-move positions have their planes swapped."""
     planes = np.ascontiguousarray(planes, dtype=np.uint64)
     lead, (two, w, nenv) = planes.shape[:-3], planes.shape[-3:]
     assert two == 2 and w == words_per_plane(m, n)
+    if side is not None:
+        swap = np.asarray(side).astype(bool)[..., None, None, :]
+        planes = np.where(swap, planes[..., ::-1, :, :], planes)
     r = record_words(m, n)
     lo = planes & np.uint64(0xFFFFFFFF)
     hi = planes >> np.uint64(32)
@@ -88,8 +92,8 @@ def record_rows(planes: np.ndarray, m: int, n: int) -> np.ndarray:
     return halves[..., 0, :, :] | (halves[..., 1, :, :] << np.uint64(32))
 
 
-def planes_from_record_rows(rows: np.ndarray, m: int, n: int) -> np.ndarray:
-    """Inverse of ``record_rows``: u64[..., R, N] -> u64[..., 2, W, N]."""
+def planes_from_record_rows(rows: np.ndarray, m: int, n: int, side=None) -> np.ndarray:
+    """Inverse of ``record_rows``: u64[..., R, N] -> absolute planes u64[..., 2, W, N]."""
     rows = np.ascontiguousarray(rows, dtype=np.uint64)
     lead, (r, nenv) = rows.shape[:-2], rows.shape[-2:]
     w = words_per_plane(m, n)
@@ -98,4 +102,8 @@ def planes_from_record_rows(rows: np.ndarray, m: int, n: int) -> np.ndarray:
     halves[..., 0, :r, :] = rows & np.uint64(0xFFFFFFFF)
     halves[..., 1, :r, :] = rows >> np.uint64(32)
     pairs = halves.reshape(lead + (2, w, 2, nenv))
-    return pairs[..., 0, :] | (pairs[..., 1, :] << np.uint64(32))
+    planes = pairs[..., 0, :] | (pairs[..., 1, :] << np.uint64(32))
+    if side is not None:
+        swap = np.asarray(side).astype(bool)[..., None, None, :]
+        planes = np.where(swap, planes[..., ::-1, :, :], planes)
+    return planes

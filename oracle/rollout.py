@@ -40,7 +40,7 @@ def random_rollout(env, seed: int, step0: int, steps: int, env_id0: int = 0):
     """Run ``steps`` random plies on every env of ``env`` (an OracleVectorEnv).
 
     Returns (rec_planes u64[T,R,N], rec_meta u32[T,N], stats i64[5]) where the
-    planes are the absolute boards *before* the ply as record rows (``packing.record_rows``) and stats =
+    planes are the boards *before* the ply as record rows, mover's plane first (``packing.record_rows``), and stats =
     [episodes finished, black wins, white wins, draws, sum of finished-episode lengths].
     """
     m, n = env.m, env.n
@@ -51,7 +51,7 @@ def random_rollout(env, seed: int, step0: int, steps: int, env_id0: int = 0):
     for t in range(steps):
         before = env.observe()
         side = env.current_player.numpy().copy()
-        rec_planes.append(record_rows(pack_boards(before["observation"].numpy(), m, n), m, n))
+        rec_planes.append(record_rows(pack_boards(before["observation"].numpy(), m, n), m, n, side))
         x = philox.rand_u32(seed, ids, step0 + t, philox.STREAM_MOVE)
         act = philox.pick_legal(before["action_mask"].numpy(), x)
         _, rew, done = env.step(torch.from_numpy(act))
@@ -80,7 +80,7 @@ def replay_actions(env, actions):
     rec_planes, rec_meta = [], []
     for act in np.asarray(actions, dtype=np.int64):
         side = env.current_player.numpy().copy()
-        rec_planes.append(record_rows(pack_boards(env.boards.numpy(), m, n), m, n))
+        rec_planes.append(record_rows(pack_boards(env.boards.numpy(), m, n), m, n, side))
         _, rew, done = env.step(torch.from_numpy(act))
         done_np = done.numpy()
         rec_meta.append(encode_record(act, rew.numpy().astype(np.int64), done_np, side))

@@ -242,8 +242,8 @@ __device__ __forceinline__ void plane_store(const uint32_t (&x)[NW], uint64_t* p
 }
 
 // ---------------------------------------------------------------- rollout records
-// One recorded position is NW u64 rows of stride N: row w = black word w | white word w << 32 (the
-// 32-bit words of the two planes, interleaved).  No padding at any board size -- 9x9 takes 3 rows =
+// One recorded position is NW u64 rows of stride N: row w = first plane's word w | second plane's word w << 32
+// (the 32-bit words of two planes, interleaved; the rollout records the mover's plane first).  No padding at any board size -- 9x9 takes 3 rows =
 // 24 B where the state layout's two u64 planes take 32 -- and the rollout is bound by exactly these
 // stores.  nw = the board's word count (MnkGeom::NW), used when NW is only an upper bound.
 template <int NW, bool EXACT = false>

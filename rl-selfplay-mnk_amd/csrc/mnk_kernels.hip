@@ -498,10 +498,9 @@ k_unpack_records(MnkGeom g, const uint64_t* rec_planes, const uint32_t* rec_meta
     if (dones) dones[t * N + i] = (uint8_t)((mw >> MNK_REC_DONE_BIT) & 1u);
     if (emit) {
       uint32_t p0[NW], p1[NW];
+      // a record is already in the mover's view (mover's words low, other side's high): channel 0 = p0
       rec_load<NW>(p0, p1, rec_planes + t * g.NW * N, N, g.NW, i);
-      const bool flip = ((mw >> MNK_REC_SIDE_BIT) & 1u) != 0;  // the mover sees itself in channel 0
-      if (flip) mnk_stage_put<NW>(st, g, B, tid, p1, p0, false);
-      else mnk_stage_put<NW>(st, g, B, tid, p0, p1, false);
+      mnk_stage_put<NW>(st, g, B, tid, p0, p1, false);
     }
   }
   if (emit) {

@@ -68,15 +68,13 @@ struct RolloutLane {
     plane_store<NW, EXACT>(p1, dst + (int64_t)g.W * N, N, g.W, i);
   }
 
-  // the position before a ply as one record (rec_store's row layout), cursor moves on to the next ply
+  // the position before a ply as one record -- mover's word | other side's word << 32, exactly the register
+  // form, so no select on the side bit (it travels in the ply's meta word) -- cursor moves on to the next ply
   __device__ __forceinline__ void store_record() {
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      if (EXACT || w < g.NW) {
-        const uint32_t black = side ? oth[w] : cur[w], white = side ? cur[w] : oth[w];
-        __builtin_nontemporal_store((uint64_t)black | ((uint64_t)white << 32), rp + (int64_t)w * N);
-      }
-    }
+    for (int w = 0; w < NW; ++w)
+      if (EXACT || w < g.NW)
+        __builtin_nontemporal_store((uint64_t)cur[w] | ((uint64_t)oth[w] << 32), rp + (int64_t)w * N);
     rp += (int64_t)g.NW * N;
   }
 

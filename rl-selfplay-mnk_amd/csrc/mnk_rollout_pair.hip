@@ -75,7 +75,7 @@ struct PairLane {
   MnkEnv<NW> e;
   int64_t N;
   uint32_t role;      // 0 / 1 within the pair
-  uint32_t* rp = nullptr;  // half `role` of rec_planes[t][0][env]: lane 0 writes the black words, lane 1 the white
+  uint32_t* rp = nullptr;  // half `role` of rec_planes[t][0][env]: lane 0 writes the mover's words, lane 1 the other side's
   uint32_t* rm = nullptr;  // rec_meta[t][env]
   uint8_t* ra = nullptr;   // act_log[t / 4][env]
   uint64_t quad = 0;       // four actions, 8 or 16 bits each (ACT = 1 / 2)
@@ -94,12 +94,13 @@ struct PairLane {
       quad |= (uint64_t)(uint32_t)a << (8 * ACT * field);
       if (field == 3) flush_log();
     }
-    if (RECORD) {  // lane `role` writes its half of every row of the board before the ply: one 256-byte store per wave
+    const uint32_t side = e.meta & 1u;
+    if (RECORD) {  // lane 0 writes the mover's word of every row, lane 1 the other side's: one 256-byte store per wave
+      const bool white_half = (role ^ side) != 0;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) rp[(int64_t)w * 2 * N] = role ? e.p[1][w] : e.p[0][w];
+      for (int w = 0; w < NW; ++w) rp[(int64_t)w * 2 * N] = white_half ? e.p[1][w] : e.p[0][w];
       rp += (int64_t)NW * 2 * N;
     }
-    const uint32_t side = e.meta & 1u;
     const uint32_t bit = (uint32_t)a + (uint32_t)a / (uint32_t)CN;
     const int wsel = (int)(bit >> 5);
     const uint32_t one = 1u << (bit & 31u);

@@ -7,8 +7,9 @@ SURVEY.md Appendix A -- ``RandomPolicy.act`` (``src/selfplay/policy.py:18-29``) 
 every env run inside ``mnk_rollout_random`` with the state in registers; what reaches
 HBM is the packed record of each ply:
 
-    planes  u64[T][R][N]      the board *before* the ply: row w = black word w | white word w << 32
-                              (32-bit words of the absolute planes; R = ceil(m*(n+1)/32), no padding)
+    planes  u64[T][R][N]      the board *before* the ply, in the mover's view: row w = mover's word w |
+                              other side's word w << 32 (32-bit words of the two planes; R = ceil(m*(n+1)/32),
+                              no padding; the mover's colour is the side bit of the same ply's meta word)
     meta    u32[T][N]         action | reward << 16 | done << 24 | mover side << 25
 
 Envs are independent, so a node shards them by contiguous blocks: rank r owns global

@@ -200,16 +200,19 @@ def test_full_size_rollout_properties(hip):
     env = hip.Env(m, n, k, nenv, device=DEV)
     roll = hip.Rollout(env, seed=1)
     rec = roll.run(steps)
-    rows = rec.planes  # [T,R,N] int64: black word | white word << 32
-    planes = torch.stack([rows & 0xFFFFFFFF, (rows >> 32) & 0xFFFFFFFF], dim=1)  # [T,2,R,N] 32-bit words
+    rows = rec.planes  # [T,R,N] int64: mover's word | other side's word << 32
+    side = rec.sides()
+    done = rec.dones()
+    lo, hi = rows & 0xFFFFFFFF, (rows >> 32) & 0xFFFFFFFF
+    white_moves = (side == 1).unsqueeze(1)
+    planes = torch.stack([torch.where(white_moves, hi, lo), torch.where(white_moves, lo, hi)], dim=1)  # [T,2,R,N] absolute
+    del lo, hi
     act = rec.actions()
     bit = act + act // n
     word, sh = bit >> 5, bit & 31
     occ = planes[:, 0] | planes[:, 1]  # [T,R,N]
     occ_at = torch.gather(occ, 1, word.unsqueeze(1)).squeeze(1)
     assert not bool(((occ_at >> sh) & 1).any()), "an occupied cell was played"
-    side = rec.sides()
-    done = rec.dones()
     stone = torch.zeros_like(planes[:-1])
     one = (torch.ones_like(sh) << sh)[:-1]
     for p in (0, 1):
@@ -249,7 +252,7 @@ def test_action_log_replay_rebuilds_the_records(hip, m, n, k, nenv, steps):
         actions = unpack_action_log(rec.act, steps)
         assert torch.equal(actions, rec.actions())
         # the chunk-start state travels with the log (state layout; the first record is the same position)
-        assert np.array_equal(record_rows(rec.planes0.cpu().numpy().view(np.uint64), m, n),
+        assert np.array_equal(record_rows(rec.planes0.cpu().numpy().view(np.uint64), m, n, rec.meta0.cpu().numpy() & 1),
                               rec.planes[0].cpu().numpy().view(np.uint64))
         logs = GatheredLogs.empty(1, env.words, nenv, steps, m * n, DEV)
         logs.msg.copy_(rec.msg.unsqueeze(0))  # what a one-rank all-gather delivers

@@ -276,7 +276,7 @@ def test_unpack_records_matches_numpy(hip, m, n, k, nenv, steps):
     meta = rec.meta.cpu().numpy().view(np.uint32)
     side = (meta >> 25) & 1
     for t in range(steps):
-        dense = unpack_boards(planes_from_record_rows(planes[t], m, n), m, n)
+        dense = unpack_boards(planes_from_record_rows(planes[t], m, n, side[t]), m, n)  # absolute planes
         flip = side[t] == 1
         dense[flip] = dense[flip][:, ::-1]
         assert np.array_equal(buf["observations"][t].cpu().numpy(), dense)
