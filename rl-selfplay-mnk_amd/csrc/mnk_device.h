@@ -70,7 +70,16 @@ __device__ __forceinline__ bool bs_has_run(const uint32_t (&b)[NW], int d, int k
     for (int w = 0; w < NW; ++w) x[w] &= t[w];
     len *= 2;
   }
-  if (len < k) {
+  if (len + 1 == k) {
+    // one stone short (k = 3, 5, 9, ...): AND with the string itself, shifted by len*d.  Same result as the
+    // general step below, but the large shift moves zeros into the top words, so the compiler drops
+    // everything that only fed those words (9x9x5: 12 instead of 15 ops for each of the three long strides)
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t[w] = b[w];
+    bs_shr<NW>(t, len * d);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) x[w] &= t[w];
+  } else if (len < k) {
 #pragma unroll
     for (int w = 0; w < NW; ++w) t[w] = x[w];
     bs_shr<NW>(t, (k - len) * d);

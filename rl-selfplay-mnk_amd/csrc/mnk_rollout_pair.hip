@@ -3,16 +3,17 @@
 #include "mnk_host.h"
 
 // ------------------------------------------------------------------ two lanes per env
-// For SMALL batches.  With fewer than 64 envs per SIMD of the chip (< 65 536 envs) the kernel above leaves
+// For SMALL batches.  With at most 32 envs per SIMD of the chip (<= 32 768 envs) the one-lane kernel leaves
 // SIMDs empty.  This variant gives every env to a PAIR of adjacent lanes -- 32 envs per wave, twice the
-// waves -- and splits what splits cleanly: lane 0 scans rows + columns, lane 1 diagonals + anti-diagonals (the shift amount is
-// a per-lane VGPR; one DPP swap ORs the verdicts); lane r writes plane r of the records; each lane computes
-// every other Philox block and hands its four words to its partner by DPP.  Move selection and the state
-// update are done redundantly by both lanes (cheaper than exchanging them).  Results are bit-identical to
-// the one-lane kernel (all compile-time board geometries).  Measured (9x9x5, 256 plies): 32 768 envs 111 us vs 133 us one-lane; at 65 536 envs
-// it loses, 182 us vs 143 us -- the rollout is VALU-throughput bound (integer VALU ops retire 16 lanes per
-// clock per SIMD, so one wave per SIMD already fills ~80 % of the issue slots) and the pair form executes
-// 1.6x the instructions per env.  The launcher therefore uses it only below 40 960 envs.  // value of the partner lane (lane ^ 1): a DPP quad_perm [1,0,3,2] move, no LDS round trip
+// waves -- and splits what splits cleanly: lane 0 scans rows + columns, lane 1 diagonals + anti-diagonals (the
+// shift amount is a per-lane VGPR; one DPP swap ORs the verdicts); lane r writes half r of every record row;
+// each lane computes every other Philox block and hands its four words to its partner by DPP.  Move selection
+// and the state update are done redundantly by both lanes (cheaper than exchanging them).  Results are
+// bit-identical to the one-lane kernel (all compile-time board geometries).  The pair form executes 1.6x the
+// instructions per env, so it wins exactly while both lanes of every env fit one wave per SIMD (2N <= 65 536
+// lanes) and the launcher uses it only up to 32 768 envs.
+
+// value of the partner lane (lane ^ 1): a DPP quad_perm [1,0,3,2] move, no LDS round trip
 __device__ __forceinline__ uint32_t pair_swap(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
 }
@@ -36,9 +37,9 @@ __device__ __forceinline__ void bs_shr_pair(uint32_t (&x)[NW], uint32_t role) {
   for (int w = 0; w < NW; ++w) x[w] = __builtin_amdgcn_alignbit(y[w + 1], y[w], r);
 }
 
-// run-doubling scan (see bs_has_run) with the direction stride D0 on role 0 and D1 on role 1
+// run-doubling scan (see bs_has_run) with the direction stride D0 on role 0 and D1 on role 1; b = the plane
 template <int NW, int CK, int D0, int D1, int LEN = 1>
-__device__ __forceinline__ void bs_run_pair_steps(uint32_t (&x)[NW], uint32_t role) {
+__device__ __forceinline__ void bs_run_pair_steps(uint32_t (&x)[NW], const uint32_t (&b)[NW], uint32_t role) {
   if constexpr (2 * LEN <= CK) {
     uint32_t t[NW];
 #pragma unroll
@@ -46,7 +47,14 @@ __device__ __forceinline__ void bs_run_pair_steps(uint32_t (&x)[NW], uint32_t ro
     bs_shr_pair<NW, LEN * D0, LEN * D1>(t, role);
 #pragma unroll
     for (int w = 0; w < NW; ++w) x[w] &= t[w];
-    bs_run_pair_steps<NW, CK, D0, D1, 2 * LEN>(x, role);
+    bs_run_pair_steps<NW, CK, D0, D1, 2 * LEN>(x, b, role);
+  } else if constexpr (LEN + 1 == CK) {  // one stone short: AND with the plane itself (see bs_has_run)
+    uint32_t t[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t[w] = b[w];
+    bs_shr_pair<NW, LEN * D0, LEN * D1>(t, role);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) x[w] &= t[w];
   } else if constexpr (LEN < CK) {
     uint32_t t[NW];
 #pragma unroll
@@ -62,7 +70,7 @@ __device__ __forceinline__ uint32_t bs_run_bits_pair(const uint32_t (&b)[NW], ui
   uint32_t x[NW];
 #pragma unroll
   for (int w = 0; w < NW; ++w) x[w] = b[w];
-  bs_run_pair_steps<NW, CK, D0, D1>(x, role);
+  bs_run_pair_steps<NW, CK, D0, D1>(x, b, role);
   uint32_t any = 0;
 #pragma unroll
   for (int w = 0; w < NW; ++w) any |= x[w];
