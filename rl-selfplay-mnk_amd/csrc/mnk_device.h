@@ -193,7 +193,9 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = mnk_mul_wide(c0, M0), p1 = mnk_mul_wide(c2, M1);
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    // three-input xor in one slot (v_bitop3_b32, truth table 0x96); left alone the compiler emits two v_xor_b32
+    const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
+    const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
     c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }

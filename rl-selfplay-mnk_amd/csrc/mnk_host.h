@@ -110,6 +110,11 @@ inline int mnk_block_threads() {
 #define MNK_K(name) HIP_KERNEL_NAME(name<NW, CN, CK>)
 
 
+// one-lane rollout variants that write the action log (mnk_rollout_log.hip); act_bytes is 1 or 2
+void mnk_launch_rollout_log(const MnkGeom& g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed,
+                            uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
+                            void* act_log, int act_bytes, void* stream);
+
 // two-lanes-per-env rollout variants (mnk_rollout_pair.hip); geometry must be one of the compile-time boards
 void mnk_launch_rollout_pair(const MnkGeom& g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed,
                              uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,

@@ -1,0 +1,218 @@
+// mnk_rollout_lane.h -- the fused random-policy rollout kernel template (gfx950 / MI355X only), shared by the
+// translation units that instantiate it: mnk_rollout.hip (no action log; also the replay kernel) and
+// mnk_rollout_log.hip (the action-log variants).  Split so that the many instantiations compile in parallel.
+#pragma once
+#include "mnk_host.h"
+
+// ------------------------------------------------------------------ fused random rollout
+// T plies per env in one launch; state lives in registers, HBM sees one load and one
+// store of the state per launch plus the 28-byte (9x9) record of every ply.
+// The loop is laid out for a wave that is alone on its SIMD (65 536 envs = 1024 waves =
+// one per SIMD): no divergent branch, per-lane bookkeeping instead of per-ply ballots
+// (scalar round trips), four plies per Philox block with the word picked at compile time.
+// ACT = bytes per action of the optional action log (0 = none, 1 = u8, 2 = u16).  The log is stored
+// four plies per word -- u32[ceil(T/4)][N] (ACT 1) or u64[ceil(T/4)][N] (ACT 2), action of ply 4q+j in
+// field j of word [q][i] -- so a wave writes 256 / 512 contiguous bytes per store and the field position is a
+// compile-time constant in the unrolled loop: +7 % kernel time.  (One byte store per lane per ply, and a packed
+// word with a run-time field index, were both measured at +20 %.)
+template <int NW, int CN, int CK, bool RECORD, int ACT = 0>
+struct RolloutLane {
+  static constexpr bool EXACT = CN != 0;
+  const MnkGeom& g;
+  // The env in "mover first" form: cur = plane of the side to move, oth = the other plane.  A ply then ORs
+  // one bit into cur, scans cur and swaps the two names (free: the loop is unrolled) -- no per-word selects
+  // on the side bit as with (black, white) planes.  Black/white order is restored only where memory sees it.
+  uint32_t cur[NW], oth[NW];
+  uint32_t side, moves;
+  int64_t N;
+  // this lane's cursors into the record arrays; they advance by one ply's stride after every ply
+  uint64_t* rp = nullptr;  // rec_planes[t][0][i]
+  uint32_t* rm = nullptr;  // rec_meta[t][i]
+  uint8_t* ra = nullptr;   // act_log[t / 4][i]
+  uint64_t quad = 0;       // the actions of the current group of four plies
+  // per-lane statistics, one add each per ply (T <= 65535 per launch): draws = done - wins, black wins =
+  // wins - white wins; the summed length of the finished games needs no counter at all -- every ply adds one
+  // to `moves` and a finished game takes its length out, so it is moves(start) + T - moves(end)
+  uint32_t acc_done = 0, acc_win = 0, acc_white = 0;
+  uint32_t moves_in = 0;
+
+  __device__ __forceinline__ RolloutLane(const MnkGeom& g_, int64_t N_, int64_t i, uint64_t* rec_planes,
+                                         uint32_t* rec_meta, void* act_log)
+      : g(g_), N(N_) {
+    if (RECORD) { rp = rec_planes + i; rm = rec_meta + i; }
+    if (ACT) ra = (uint8_t*)act_log + i * 4 * ACT;
+  }
+
+  __device__ __forceinline__ void load(const uint64_t* planes, const uint32_t* meta, int64_t i) {
+    uint32_t p0[NW], p1[NW];
+    plane_load<NW, EXACT>(p0, planes, N, g.W, i);
+    plane_load<NW, EXACT>(p1, planes + (int64_t)g.W * N, N, g.W, i);
+    const uint32_t mw = meta[i];
+    side = mw & 1u;
+    moves = moves_in = mw >> 1;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      cur[w] = side ? p1[w] : p0[w];
+      oth[w] = side ? p0[w] : p1[w];
+    }
+  }
+
+  // (black, white) planes of the current position to memory at `dst`
+  __device__ __forceinline__ void store_planes(uint64_t* dst, int64_t i) const {
+    uint32_t p0[NW], p1[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      p0[w] = side ? oth[w] : cur[w];
+      p1[w] = side ? cur[w] : oth[w];
+    }
+    plane_store<NW, EXACT>(p0, dst, N, g.W, i);
+    plane_store<NW, EXACT>(p1, dst + (int64_t)g.W * N, N, g.W, i);
+  }
+
+  // the position before a ply as one record -- mover's word | other side's word << 32, exactly the register
+  // form, so no select on the side bit (it travels in the ply's meta word) -- cursor moves on to the next ply
+  __device__ __forceinline__ void store_record() {
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+      if (EXACT || w < g.NW)
+        __builtin_nontemporal_store((uint64_t)cur[w] | ((uint64_t)oth[w] << 32), rp + (int64_t)w * N);
+    rp += (int64_t)g.NW * N;
+  }
+
+  __device__ __forceinline__ void store(uint64_t* planes, uint32_t* meta, int64_t i) const {
+    store_planes(planes, i);
+    meta[i] = (moves << 1) | side;
+  }
+
+  __device__ __forceinline__ void log_flush() {
+    if (ACT == 1) *(uint32_t*)ra = (uint32_t)quad;
+    if (ACT == 2) *(uint64_t*)ra = quad;
+    ra += N * 4 * ACT;
+    quad = 0;
+  }
+
+  // uniform legal cell from one u32 (oracle/philox.py pick_legal; selfplay/policy.py:18-29): the action, and
+  // the cell's bit as a one-hot string
+  __device__ __forceinline__ int pick(uint32_t x, uint32_t (&hot)[NW]) const {
+    uint32_t legal[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) legal[w] = ~(cur[w] | oth[w]) & g.valid[w];
+    const int nl = bs_popcount<NW>(legal);
+    int n = nl;
+    // full board (poked states only): any cell, like RandomPolicy's 1e-8 guard -- the r-th valid cell is cell r.
+    // A wave-uniform branch that is practically never taken: one compare and one scalar branch per ply.
+    if (__builtin_amdgcn_ballot_w64(nl == 0) != 0) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) legal[w] = nl ? legal[w] : g.valid[w];
+      n = nl ? nl : g.C;
+    }
+    const int r = (int)__umulhi(x, (uint32_t)n);
+    const uint32_t bit = (uint32_t)bs_select_hot<NW>(legal, r, hot);
+    return (int)(bit - (CN ? bit / (uint32_t)(CN + 1) : mnk_div(bit, g.magic_stride)));
+  }
+
+  // field = position of this ply inside its group of four (= step & 3; a compile-time constant in
+  // the unrolled main loop, so the log costs one shift-or per ply and one wide store per four)
+  __device__ __forceinline__ void ply(uint32_t x, int field) {
+    uint32_t hot[NW];
+    const int a = pick(x, hot);
+    if (ACT) {
+      quad |= (uint64_t)(uint32_t)a << (8 * ACT * field);
+      if (field == 3) log_flush();
+    }
+    ply_hot(a, hot);
+  }
+
+  // one ply with a known-good action (from an action log the sampler wrote)
+  __device__ __forceinline__ void ply_action(int a) {
+    const uint32_t ua = (uint32_t)a;
+    ply_bit(a, ua + (CN ? ua / (uint32_t)CN : mnk_div(ua, g.magic_n)));
+  }
+
+  __device__ __forceinline__ void ply_bit(int a, uint32_t bit) {
+    const int wsel = (int)(bit >> 5);
+    const uint32_t one = 1u << (bit & 31u);
+    uint32_t hot[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) hot[w] = (w == wsel) ? one : 0u;
+    ply_hot(a, hot);
+  }
+
+  // env/torch_vector_mnk_env.py:60-84 for the mover, then env.reset(nonzero(done)) :34-44
+  __device__ __forceinline__ void ply_hot(int a, const uint32_t (&hot)[NW]) {
+    if (RECORD) store_record();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) cur[w] |= hot[w];                    // :68
+    ++moves;                                                          // :69
+    const uint32_t win = mnk_plane_wins<NW, CN, CK>(g, cur) ? 1u : 0u;  // :71
+    const uint32_t done = win | (moves >= (uint32_t)g.C ? 1u : 0u);   // :72-73
+    if (RECORD) {
+      __builtin_nontemporal_store((uint32_t)a | (win << MNK_REC_REWARD_SHIFT) | (done << MNK_REC_DONE_BIT) | (side << MNK_REC_SIDE_BIT), rm);
+      rm += N;
+    }
+    acc_done += done;
+    acc_win += win;
+    acc_white += win & side;
+    // the other side is to move (:82) -- or a fresh game
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const uint32_t c = cur[w];
+      cur[w] = done ? 0u : oth[w];
+      oth[w] = done ? 0u : c;
+    }
+    side = done ? 0u : (side ^ 1u);
+    moves = done ? 0u : moves;
+  }
+};
+
+template <int NW, int CN, int CK, bool RECORD, int ACT>
+__global__ void __launch_bounds__(64)
+k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed, uint64_t step0,
+                 int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, unsigned long long* stats,
+                 void* act_log) {
+  // one full wave of 64 envs per workgroup: half-filled waves were measured and are slower
+  // (gfx950 does not skip the idle half of a wave64), see DESIGN.md
+  __shared__ unsigned int lds_stats[MNK_STATS_COUNTERS];
+  if (threadIdx.x < MNK_STATS_COUNTERS) lds_stats[threadIdx.x] = 0u;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) {
+    RolloutLane<NW, CN, CK, RECORD, ACT> L(g, N, i, rec_planes, rec_meta, act_log);
+    L.load(planes, meta, i);
+    const uint64_t env = (uint64_t)(env_id0 + i);
+    int t = 0;
+    uint64_t step = step0;
+    if (step & 3) {  // head: finish the Philox block the previous launch stopped in
+      const Philox4 blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
+      for (; t < T && (step & 3); ++t, ++step) L.ply(philox_word(blk, (uint32_t)(step & 3)), (int)(step & 3));
+    }
+    for (; t + 4 <= T; t += 4, step += 4) {
+      const Philox4 blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
+      L.ply(blk.v[0], 0);
+      L.ply(blk.v[1], 1);
+      L.ply(blk.v[2], 2);
+      L.ply(blk.v[3], 3);
+    }
+    if (t < T) {
+      const Philox4 blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
+      for (uint32_t j = 0; t < T; ++t, ++j) L.ply(philox_word(blk, j), (int)j);
+    }
+    if (ACT && (T & 3)) L.log_flush();  // T not a multiple of 4: the last word is partly filled
+    L.store(planes, meta, i);
+    if (stats) {
+      const uint32_t len_sum = L.moves_in + (uint32_t)T - L.moves;
+      if (L.acc_done) atomicAdd(&lds_stats[0], L.acc_done);
+      if (L.acc_win - L.acc_white) atomicAdd(&lds_stats[1], L.acc_win - L.acc_white);
+      if (L.acc_white) atomicAdd(&lds_stats[2], L.acc_white);
+      if (L.acc_done - L.acc_win) atomicAdd(&lds_stats[3], L.acc_done - L.acc_win);
+      if (len_sum) atomicAdd(&lds_stats[4], len_sum);
+    }
+  }
+  __syncthreads();
+  // one global atomic per counter per wave, spread over MNK_STATS_REPLICAS cache lines: thousands
+  // of adds on five addresses would serialise at ~11 ns each (measured: 56 us per launch)
+  if (stats && threadIdx.x < MNK_STATS_COUNTERS && lds_stats[threadIdx.x])
+    atomicAdd(&stats[(size_t)(blockIdx.x % MNK_STATS_REPLICAS) * MNK_STATS_STRIDE + threadIdx.x],
+              (unsigned long long)lds_stats[threadIdx.x]);
+}
+
