@@ -49,11 +49,8 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   // two lanes per env only while both lanes of every env still fit one wave per SIMD (2N <= 65 536 lanes:
   // 9x9x5 106 vs 135 us per 256 plies at 32 768 envs, 164 vs 135 at 36 864; tools/exp_pair_threshold.py)
   // (MNK_ROLLOUT_PAIR=0/1 overrides, for A/B timing)
-  static int pair_override = -2;
-  if (pair_override == -2) {
-    const char* v = getenv("MNK_ROLLOUT_PAIR");
-    pair_override = v ? atoi(v) : -1;
-  }
+  const char* pair_env = getenv("MNK_ROLLOUT_PAIR");  // read per call, so one process can time / test both forms
+  const int pair_override = pair_env ? atoi(pair_env) : -1;
   const bool pair_geom = (g.n == 9 && g.k == 5 && g.NW == 3) || (g.n == 3 && g.k == 3 && g.NW == 1) ||
                          (g.n == 13 && g.k == 5 && g.NW == 6) || (g.n == 15 && g.k == 5 && g.NW == 8) ||
                          (g.n == 19 && g.k == 5 && g.NW == 12);

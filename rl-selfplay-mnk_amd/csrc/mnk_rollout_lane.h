@@ -3,6 +3,7 @@
 // mnk_rollout_log.hip (the action-log variants).  Split so that the many instantiations compile in parallel.
 #pragma once
 #include "mnk_host.h"
+#include "mnk_pair_scan.h"
 
 // ------------------------------------------------------------------ fused random rollout
 // T plies per env in one launch; state lives in registers, HBM sees one load and one
@@ -15,7 +16,10 @@
 // field j of word [q][i] -- so a wave writes 256 / 512 contiguous bytes per store and the field position is a
 // compile-time constant in the unrolled loop: +7 % kernel time.  (One byte store per lane per ply, and a packed
 // word with a run-time field index, were both measured at +20 %.)
-template <int NW, int CN, int CK, bool RECORD, int ACT = 0>
+// PAIR: the two-lanes-per-env form for small batches (mnk_rollout_pair.hip): both lanes of a pair carry the env and
+// pick the move redundantly; lane `role` scans two of the four directions (one DPP swap ORs the verdicts), writes
+// half `role` of every record row and stores plane `role` of the final state.
+template <int NW, int CN, int CK, bool RECORD, int ACT = 0, bool PAIR = false>
 struct RolloutLane {
   static constexpr bool EXACT = CN != 0;
   const MnkGeom& g;
@@ -26,7 +30,9 @@ struct RolloutLane {
   uint32_t side, moves;
   int64_t N;
   // this lane's cursors into the record arrays; they advance by one ply's stride after every ply
+  uint32_t role = 0;       // PAIR: 0 / 1 within the lane pair
   uint64_t* rp = nullptr;  // rec_planes[t][0][i]
+  uint32_t* rp32 = nullptr;  // PAIR: half `role` of rec_planes[t][0][i]
   uint32_t* rm = nullptr;  // rec_meta[t][i]
   uint8_t* ra = nullptr;   // act_log[t / 4][i]
   uint64_t quad = 0;       // the actions of the current group of four plies
@@ -37,9 +43,13 @@ struct RolloutLane {
   uint32_t moves_in = 0;
 
   __device__ __forceinline__ RolloutLane(const MnkGeom& g_, int64_t N_, int64_t i, uint64_t* rec_planes,
-                                         uint32_t* rec_meta, void* act_log)
-      : g(g_), N(N_) {
-    if (RECORD) { rp = rec_planes + i; rm = rec_meta + i; }
+                                         uint32_t* rec_meta, void* act_log, uint32_t role_ = 0)
+      : g(g_), N(N_), role(role_) {
+    if (RECORD) {
+      if (PAIR) rp32 = (uint32_t*)(rec_planes + i) + role;
+      else rp = rec_planes + i;
+      rm = rec_meta + i;
+    }
     if (ACT) ra = (uint8_t*)act_log + i * 4 * ACT;
   }
 
@@ -72,6 +82,12 @@ struct RolloutLane {
   // the position before a ply as one record -- mover's word | other side's word << 32, exactly the register
   // form, so no select on the side bit (it travels in the ply's meta word) -- cursor moves on to the next ply
   __device__ __forceinline__ void store_record() {
+    if constexpr (PAIR) {  // lane 0 writes the mover's word of every row, lane 1 the other side's: 256 B per wave and store
+#pragma unroll
+      for (int w = 0; w < NW; ++w) __builtin_nontemporal_store(role ? oth[w] : cur[w], rp32 + (int64_t)w * 2 * N);
+      rp32 += (int64_t)NW * 2 * N;
+      return;
+    }
 #pragma unroll
     for (int w = 0; w < NW; ++w)
       if (EXACT || w < g.NW)
@@ -80,7 +96,14 @@ struct RolloutLane {
   }
 
   __device__ __forceinline__ void store(uint64_t* planes, uint32_t* meta, int64_t i) const {
-    store_planes(planes, i);
+    if constexpr (PAIR) {  // lane `role` stores plane `role` (black = the mover's plane when black is to move)
+      uint32_t mine[NW];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) mine[w] = (role ^ side) ? oth[w] : cur[w];
+      plane_store<NW, EXACT>(mine, planes + (int64_t)role * g.W * N, N, g.W, i);
+    } else {
+      store_planes(planes, i);
+    }
     meta[i] = (moves << 1) | side;
   }
 
@@ -144,7 +167,16 @@ struct RolloutLane {
 #pragma unroll
     for (int w = 0; w < NW; ++w) cur[w] |= hot[w];                    // :68
     ++moves;                                                          // :69
-    const uint32_t win = mnk_plane_wins<NW, CN, CK>(g, cur) ? 1u : 0u;  // :71
+    uint32_t win;                                                     // :71
+    if constexpr (PAIR) {
+      // role 0 scans columns and rows, role 1 diagonals and anti-diagonals; paired so that the word parts of
+      // the shift amounts agree wherever the board allows (n+1 with n+2, 1 with n)
+      uint32_t hit = bs_run_bits_pair<NW, CK, CN + 1, CN + 2>(cur, role) | bs_run_bits_pair<NW, CK, 1, CN>(cur, role);
+      hit |= pair_swap(hit);  // the partner's two directions
+      win = hit ? 1u : 0u;
+    } else {
+      win = mnk_plane_wins<NW, CN, CK>(g, cur) ? 1u : 0u;
+    }
     const uint32_t done = win | (moves >= (uint32_t)g.C ? 1u : 0u);   // :72-73
     if (RECORD) {
       __builtin_nontemporal_store((uint32_t)a | (win << MNK_REC_REWARD_SHIFT) | (done << MNK_REC_DONE_BIT) | (side << MNK_REC_SIDE_BIT), rm);

@@ -157,13 +157,64 @@ def test_sample_legal_matches_oracle(hip, m, n, k, nenv):
         assert np.array_equal(acts.cpu().numpy(), philox.pick_legal(legal, x))
 
 
+@pytest.fixture(params=["one lane per env", "two lanes per env"])
+def lanes_per_env(request):
+    """The launcher picks the rollout kernel form by batch size; MNK_ROLLOUT_PAIR (read on every call) forces it,
+    so small test batches reach the one-lane kernels of the compile-time boards too.  Boards without a
+    compile-time specialisation have the one-lane form only."""
+    import os
+    old = os.environ.get("MNK_ROLLOUT_PAIR")
+    os.environ["MNK_ROLLOUT_PAIR"] = "0" if request.param.startswith("one") else "1"
+    yield request.param
+    if old is None:
+        del os.environ["MNK_ROLLOUT_PAIR"]
+    else:
+        os.environ["MNK_ROLLOUT_PAIR"] = old
+
+
+@pytest.mark.parametrize("m,n,k", [(3, 3, 3), (9, 9, 5), (19, 19, 5), (7, 9, 7), (22, 22, 5)])
+def test_sample_legal_reaches_every_cell_and_every_rank(hip, m, n, k):
+    """The r-th-set-bit select at its edges: one env per cell with only that cell free (the draw must be that
+    cell whatever the random word), and boards with a known set of free cells where every rank is hit --
+    first and last cell, word boundaries of the bit string -- against the oracle's pick_legal."""
+    c = m * n
+    dense = np.ones((c, 2, m, n), dtype=np.float32)
+    dense[:, 1] = 0.0
+    for cell in range(c):
+        dense[cell, 0, cell // n, cell % n] = 0.0
+    env = hip.Env(m, n, k, c, device=DEV)
+    env.boards = torch.from_numpy(dense)
+    acts = torch.empty(c, dtype=torch.int64, device=DEV)
+    for step in (0, 1, 2, 3, 12345):
+        env.sample_legal_into(acts, seed=step, step=step, env_id0=0, stream_id=0)
+        assert acts.cpu().tolist() == list(range(c))
+    # free cells at the corners and around the 32-bit word boundaries of the guard-column bit string
+    bits = sorted({0, 1, 30, 31, 32, 33, 62, 63, 64, 65, 94, 95, 96, 97, m * (n + 1) - 2})
+    cells = sorted({b - b // (n + 1) for b in bits if b % (n + 1) != n and b < m * (n + 1) - 1} | {0, c - 1})
+    nenv = 4096
+    dense = np.ones((nenv, 2, m, n), dtype=np.float32)
+    dense[:, 1] = 0.0
+    for cell in cells:
+        dense[:, 0, cell // n, cell % n] = 0.0
+    env = hip.Env(m, n, k, nenv, device=DEV)
+    env.boards = torch.from_numpy(dense)
+    acts = torch.empty(nenv, dtype=torch.int64, device=DEV)
+    env.sample_legal_into(acts, seed=7, step=9, env_id0=100, stream_id=0)
+    legal = ~(dense != 0).any(axis=1).reshape(nenv, c)
+    x = philox.rand_u32(7, np.arange(100, 100 + nenv, dtype=np.uint64), 9, 0)
+    got = acts.cpu().numpy()
+    assert np.array_equal(got, philox.pick_legal(legal, x))
+    assert sorted(set(got.tolist())) == cells  # 4096 draws over <= 16 cells: every rank occurs
+
+
 @pytest.mark.parametrize("m,n,k,nenv,chunks", [(3, 3, 3, 64, (7, 9, 16)), (9, 9, 5, 333, (64, 31)),
                                                (3, 3, 3, 3, (30,)), (9, 9, 5, 1, (5, 6, 200)), (5, 6, 4, 129, (61,)),
                                                (4, 6, 3, 100, (40,)), (13, 13, 5, 65, (120,)),
                                                (19, 19, 5, 64, (200,)), (7, 9, 7, 70, (90,))])
-def test_rollout_matches_oracle(hip, m, n, k, nenv, chunks):
+def test_rollout_matches_oracle(hip, m, n, k, nenv, chunks, lanes_per_env):
     """mnk_rollout_random == oracle loop (sample -> step -> reset done), records, stats and final
-    state bit for bit; several launches continue the same Philox step counter."""
+    state bit for bit; several launches continue the same Philox step counter.  Both kernel forms: one lane per
+    env (what large batches, the headline size included, run) and two lanes per env (small batches)."""
     env = hip.Env(m, n, k, nenv, device=DEV)
     roll = hip.Rollout(env, seed=5, env_id0=12345)
     ora = OracleVectorEnv(m, n, k, nenv)
@@ -234,7 +285,7 @@ def test_full_size_rollout_properties(hip):
 
 @pytest.mark.parametrize("m,n,k,nenv,steps", [(3, 3, 3, 70, 40), (9, 9, 5, 200, 130), (19, 19, 5, 65, 90),
                                               (13, 13, 5, 5, 150), (7, 9, 7, 64, 81), (9, 9, 5, 64, 6)])
-def test_action_log_replay_rebuilds_the_records(hip, m, n, k, nenv, steps):
+def test_action_log_replay_rebuilds_the_records(hip, m, n, k, nenv, steps, lanes_per_env):
     """The multi-GPU exchange format: chunk-start state + action log (1-2 B per ply).
     mnk_replay_actions on the log == the records the rollout wrote (bit for bit) == the oracle's
     replay of the same log; a second chunk checks that the state carried over."""
