@@ -1,6 +1,7 @@
 // mnk_rollout_lane.h -- the fused random-policy rollout kernel template (gfx950 / MI355X only), shared by the
-// translation units that instantiate it: mnk_rollout.hip (no action log; also the replay kernel) and
-// mnk_rollout_log.hip (the action-log variants).  Split so that the many instantiations compile in parallel.
+// translation units that instantiate it: mnk_rollout.hip (no action log; also the replay kernel),
+// mnk_rollout_log.hip (the action-log variants) and mnk_rollout_pair.hip (two lanes per env).  Split so that
+// the many instantiations compile in parallel.
 #pragma once
 #include "mnk_host.h"
 #include "mnk_pair_scan.h"
