@@ -47,21 +47,29 @@
 extern "C" {
 #endif
 
-#define MNK_ABI_VERSION 2
+#define MNK_ABI_VERSION 3
 
 /* status codes (host-side argument checks) */
 #define MNK_OK 0
 #define MNK_EINVAL -1   /* null pointer / negative size */
 #define MNK_EGEOM -2    /* unsupported board geometry (see mnk_geometry_supported) */
 #define MNK_ELAUNCH -3  /* hipLaunchKernel failed (hipGetLastError text via mnk_last_launch_error) */
+#define MNK_ECOMM -4    /* an RCCL call failed or librccl could not be resolved (text via mnk_comm_last_error) */
 
 /* device-side error codes written to err[0] */
 #define MNK_ERR_NONE 0
 #define MNK_ERR_ACTION_RANGE 1 /* action outside [-m*n, m*n): the reference raises IndexError (env/torch_vector_mnk_env.py:68) */
 #define MNK_ERR_ILLEGAL_MOVE 2 /* strict mode only: occupied cell, message of env/torch_vector_mnk_env.py:102-104 */
 
-/* flags for mnk_step */
+/* flags for mnk_step and the mnk_selfplay_* functions */
 #define MNK_STEP_STRICT 1u /* refuse moves onto occupied cells (the behaviour tests/test_mnk_integration.py:68-81 expects) */
+
+/* element type of the logits handed to mnk_sample_logits */
+#define MNK_LOGITS_F32 0
+#define MNK_LOGITS_BF16 1 /* what the reference's networks emit under alg/ppo.py:194 autocast on Ampere+ (utils/hardware.py:38-41) */
+
+/* bytes of the opaque communicator id exchanged between ranks (= NCCL_UNIQUE_ID_BYTES) */
+#define MNK_COMM_ID_BYTES 128
 
 /* flags written by mnk_selfplay_pre for mnk_selfplay_post (u8 per env) */
 #define MNK_SP_NEED_OPP 1u
@@ -139,13 +147,15 @@ int mnk_unpack_boards(const uint64_t* planes, float* boards, int64_t N, int m, i
 int mnk_sample_legal(const uint64_t* planes, int64_t N, int m, int n, uint64_t seed, uint64_t step,
                      const uint64_t* step_dev, int64_t env_id0, int stream_id, int64_t* actions, void* stream);
 
-/* ---- alg/architectures/cnn.py:69-79 (= resnet.py:84-95, transformer.py:80-91) + policy.py:46-52
- * Masked categorical head fused with the draw: logits f32[N][C] (any additive normalisation),
- * mask u8[N][C], C <= 512.  deterministic != 0 -> argmax over legal cells (policy.py:48-49); else an
- * inverse-CDF draw from softmax(masked logits) with one Philox uniform per row (stream MNK_STREAM_SAMPLE).
+/* ---- alg/architectures/cnn.py:69-79 (= resnet.py:84-95, transformer.py:80-91) + policy.py:46-52 + ppo.py:96-97
+ * Masked categorical head fused with the draw: logits [N][C] of type `logits_dtype` (MNK_LOGITS_F32: float,
+ * MNK_LOGITS_BF16: bf16 bit patterns; any additive normalisation), mask u8[N][C], C <= 512.
+ * logits == NULL: every logit is 0 -- a uniform draw over the legal cells (RandomPolicy, policy.py:13-29) that
+ * reads only the mask.  deterministic != 0 -> argmax over legal cells (policy.py:48-49); else an inverse-CDF draw
+ * from softmax(masked logits) with one Philox uniform per row (stream MNK_STREAM_SAMPLE).
  * All-masked row -> uniform over C (cnn.py:76-77).
- * logp (optional) = log-probability of the chosen action under the masked softmax. */
-int mnk_sample_logits(const float* logits, const uint8_t* mask, int64_t N, int C, uint64_t seed,
+ * logp (optional) = log-probability of the chosen action under the masked softmax (f32 arithmetic). */
+int mnk_sample_logits(const void* logits, int logits_dtype, const uint8_t* mask, int64_t N, int C, uint64_t seed,
                       uint64_t step, const uint64_t* step_dev, int64_t env_id0, int deterministic,
                       int64_t* actions, float* logp, void* stream);
 
@@ -162,13 +172,15 @@ int mnk_selfplay_pre(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, 
                      const int64_t* actions, const uint8_t* pending, int64_t* agent_side,
                      const int64_t* forced_side, uint64_t seed, uint64_t step, const uint64_t* step_dev,
                      int64_t env_id0, float* rewards, uint8_t* terminated, uint8_t* sp_flags,
-                     float* opp_obs, uint8_t* opp_mask, int32_t* err, void* stream);
+                     float* opp_obs, uint8_t* opp_mask, int32_t* err, uint32_t flags, void* stream);
 int mnk_selfplay_post(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k,
                       const int64_t* opp_actions, const uint8_t* sp_flags, const int64_t* agent_side,
                       float* rewards, uint8_t* terminated, uint8_t* pending,
                       float* obs, uint8_t* legal_mask, int32_t* err,
-                      float* ep_return, int32_t* ep_length, int64_t* ep_stats, void* stream);
-/* ep_* (all three or none; NULL = off): device-side episode accounting replacing the host loop of
+                      float* ep_return, int32_t* ep_length, int64_t* ep_stats, uint32_t flags, void* stream);
+/* flags: MNK_STEP_STRICT makes an agent / opponent move onto an occupied cell an MNK_ERR_ILLEGAL_MOVE (the env is
+ * left untouched) instead of the reference's silent overwrite (env/torch_vector_mnk_env.py:67-69).
+ * ep_* (all three or none; NULL = off): device-side episode accounting replacing the host loop of
  * alg/ppo.py:110-120 (dones.any() + nonzero + tolist, two synchronisations per step).  ep_return f32[N] /
  * ep_length i32[N] carry the running return and length (agent-steps) of each env's current episode; when
  * an env terminates its episode is added to ep_stats = int64[MNK_STATS_REPLICAS][MNK_STATS_STRIDE]
@@ -180,7 +192,7 @@ int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m,
                              const int64_t* forced_side, uint64_t seed, uint64_t step, const uint64_t* step_dev,
                              int64_t env_id0, float* rewards, uint8_t* terminated, float* obs, uint8_t* legal_mask,
                              int32_t* err, float* ep_return, int32_t* ep_length, int64_t* ep_stats,
-                             void* stream);
+                             uint32_t flags, void* stream);
 
 /* ---- the random-policy rollout of BASELINE.json (RandomPolicy.act -> env.step -> env.reset(done)),
  * T plies per env in one launch with the state held in registers.
@@ -226,6 +238,25 @@ int mnk_gather_obs(const uint64_t* planes, int64_t T, int64_t N, int m, int n, c
 int mnk_gae(const float* rewards, const float* values, const uint8_t* dones, const float* last_values,
             int64_t N, int T, float gamma, float gamma_lambda, float* advantages, float* returns,
             void* stream);
+
+/* ---- the exchange step of the sharded rollout: RCCL all-gather over xGMI ------------
+ * The reference has no distributed code; what ranks exchange is the content of its RolloutBuffer
+ * (alg/rollout_buffer.py:14-44) in the packed forms above -- either the records themselves or the message
+ * "chunk-start planes | action log | chunk-start meta" that mnk_replay_actions expands on the receiver.
+ * One process per GPU.  mnk_comm_unique_id (one rank, HOST buffer of MNK_COMM_ID_BYTES) -> the id travels to
+ * the other ranks by any host channel (torch.distributed store, a file, MPI) -> every rank calls mnk_comm_init
+ * with its rank on its current HIP device -> mnk_allgather_records enqueues ONE all-gather of `bytes` bytes per
+ * rank on `stream` (recv holds nranks * bytes; rank r's message lands at recv + r * bytes; in-place allowed
+ * when send == recv + rank * bytes) -> mnk_comm_destroy.  Only enqueues: ordering against the rollout kernel
+ * is by stream / events, as for every other entry point.  RCCL is resolved from the librccl.so.1 the process
+ * has already loaded (PyTorch-ROCm's), not linked.  Errors: MNK_ECOMM + mnk_comm_last_error(). */
+int mnk_comm_unique_id(void* id_out_host);
+int mnk_comm_init(void** comm_out, const void* id_host, int nranks, int rank);
+int mnk_comm_destroy(void* comm);
+int mnk_allgather_records(void* comm, const void* send, void* recv, int64_t bytes, void* stream);
+const char* mnk_comm_last_error(void);
+/* NCCL_VERSION_CODE of the resolved library, 0 when none could be resolved */
+int mnk_comm_version(void);
 
 #ifdef __cplusplus
 }

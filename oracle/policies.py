@@ -100,3 +100,52 @@ class PhiloxOpponent:
         ids = (idx.numpy() + self.env_id0).astype(np.uint64)
         x = philox.rand_u32(self.seed, ids, self.step, philox.STREAM_OPP)
         return torch.from_numpy(philox.pick_legal(obs["action_mask"].numpy(), x))
+
+
+def _rth_legal(mask, r):
+    """index of the r-th legal cell of every row (r already reduced mod the row's legal count); 0 when none"""
+    nl = mask.sum(dim=1)
+    rank = torch.cumsum(mask, dim=1) - 1
+    pick = (mask == 1) & (rank == r.unsqueeze(1))
+    act = torch.argmax(pick.to(torch.int64), dim=1)
+    return torch.where(nl > 0, act, torch.zeros_like(act))
+
+
+def _mask_hash(mask, salt=0):
+    c = mask.shape[1]
+    a = torch.arange(c, device=mask.device, dtype=torch.int64)
+    return (mask * (a * a * 31 + a * 7 + 3 + salt)).sum(dim=1)
+
+
+class RowSaltedHashPolicy:
+    """MaskHashPolicy whose hash also mixes in the row's position in the batch it is called on.  For callers
+    that hand the policy the FULL env batch on every call (the agent side of ``validate_gpu``,
+    validation.py:23-24): every env then plays its own game although all start from the same position."""
+
+    def __init__(self, salt: int = 0):
+        self.salt = int(salt)
+
+    def act(self, obs, deterministic: bool = False):
+        mask = obs["action_mask"].to(torch.int64)
+        row = torch.arange(mask.shape[0], device=mask.device, dtype=torch.int64)
+        h = _mask_hash(mask, self.salt) + row * 7919 + (row * row) % 1013
+        return _rth_legal(mask, torch.remainder(h, torch.clamp(mask.sum(dim=1), min=1)))
+
+
+class OpeningByRowPolicy:
+    """Row-position-dependent while fewer than ``open_plies`` stones are on the board, MaskHashPolicy after that.
+    For the tournament loop (match_runner.py:149-196): the reference hands policies ``obs[is_turn]`` subsets, the
+    HIP loop the full batch -- during the first two plies no game can be over (k >= 2), both pass all rows in env
+    order, so the opening may depend on the row; afterwards the action depends on the row's mask alone."""
+
+    def __init__(self, salt: int = 0, open_plies: int = 2):
+        self.salt, self.open_plies = int(salt), int(open_plies)
+
+    def act(self, obs, deterministic: bool = False):
+        mask = obs["action_mask"].to(torch.int64)
+        c = mask.shape[1]
+        nl = mask.sum(dim=1)
+        row = torch.arange(mask.shape[0], device=mask.device, dtype=torch.int64)
+        opening = (c - nl) < self.open_plies
+        h = torch.where(opening, row * 40503 + self.salt * 17 + 11, _mask_hash(mask, self.salt))
+        return _rth_legal(mask, torch.remainder(h, torch.clamp(nl, min=1)))

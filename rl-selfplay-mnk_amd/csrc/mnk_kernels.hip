@@ -188,14 +188,14 @@ struct SpAgent {
 template <int NW, int CN, int CK>
 __device__ __forceinline__ SpAgent sp_agent_half(const MnkGeom& g, MnkEnv<NW>& e, int64_t action, bool pending,
                                                  int64_t& side, const int64_t* forced_side, uint64_t seed,
-                                                 uint64_t step, uint64_t env, int64_t i, int32_t* err) {
+                                                 uint64_t step, uint64_t env, int64_t i, int32_t* err, bool strict) {
   SpAgent a;
   a.reward = 0.0f; a.term = false; a.was_reset = pending;
   if (pending) {
     env_clear<NW>(e);  // wrapper:41 env.reset(reset_idxs)
     side = forced_side ? (forced_side[i] & 1) : (int64_t)(mnk_rand_u32(seed, env, step, MNK_STREAM_SIDE) >> 31);  // :43-45
   } else {
-    const MnkPly ply = env_play<NW, CN, CK>(g, e, action, false);  // :51
+    const MnkPly ply = env_play<NW, CN, CK>(g, e, action, strict);  // :51
     if (ply.err) mnk_report(err, ply.err, i);
     a.reward = ply.win ? 1.0f : 0.0f;  // :53
     a.term = ply.done;                 // :54
@@ -210,7 +210,8 @@ __global__ void __launch_bounds__(256)
 k_selfplay_pre(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions,
                const uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
                uint64_t step, const uint64_t* step_dev, int64_t env_id0, float* rewards, uint8_t* terminated,
-               uint8_t* sp_flags, float* opp_obs, uint8_t* opp_mask, int32_t* err, int vec_ok, int envs_per_block) {
+               uint8_t* sp_flags, float* opp_obs, uint8_t* opp_mask, int32_t* err, uint32_t flags, int vec_ok,
+               int envs_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   if (step_dev) step += *step_dev;
   const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
@@ -225,7 +226,7 @@ k_selfplay_pre(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int
     int64_t side = agent_side[i];
     const bool pend = pending[i] != 0;
     const SpAgent a = sp_agent_half<NW, CN, CK>(g, e, actions[i], pend, side, forced_side, seed, step,
-                                        (uint64_t)(env_id0 + i), i, err);
+                                        (uint64_t)(env_id0 + i), i, err, (flags & MNK_STEP_STRICT) != 0);
     env_store<NW>(e, planes, meta, N, g.W, i);
     if (pend) agent_side[i] = side;
     rewards[i] = a.reward;
@@ -251,8 +252,8 @@ template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
 k_selfplay_post(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* opp_actions,
                 const uint8_t* sp_flags, const int64_t* agent_side, float* rewards, uint8_t* terminated,
-                uint8_t* pending, float* obs, uint8_t* legal_mask, int32_t* err, MnkEpisodes ep, int vec_ok,
-                int envs_per_block) {
+                uint8_t* pending, float* obs, uint8_t* legal_mask, int32_t* err, MnkEpisodes ep, uint32_t flags,
+                int vec_ok, int envs_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   __shared__ unsigned int lds_ep[MNK_STATS_COUNTERS];
   const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
@@ -272,7 +273,7 @@ k_selfplay_post(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const in
     float rew = rewards[i];
     bool term = terminated[i] != 0;
     if (f & MNK_SP_NEED_OPP) {
-      const MnkPly ply = env_play<NW, CN, CK>(g, e, opp_actions[i], false);  // wrapper:96
+      const MnkPly ply = env_play<NW, CN, CK>(g, e, opp_actions[i], (flags & MNK_STEP_STRICT) != 0);  // wrapper:96
       if (ply.err) mnk_report(err, ply.err, i);
       else env_store<NW>(e, planes, meta, N, g.W, i);
       if (!(f & MNK_SP_WAS_RESET)) {  // :46 ignores the reply's outcome after a reset
@@ -306,7 +307,7 @@ k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, c
                        uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
                        uint64_t step, const uint64_t* step_dev, int64_t env_id0, float* rewards,
                        uint8_t* terminated, float* obs, uint8_t* legal_mask, int32_t* err, MnkEpisodes ep,
-                       int vec_ok, int envs_per_block) {
+                       uint32_t flags, int vec_ok, int envs_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   if (step_dev) step += *step_dev;
   __shared__ unsigned int lds_ep[MNK_STATS_COUNTERS];
@@ -326,7 +327,8 @@ k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, c
     int64_t side = agent_side[i];
     const bool pend = pending[i] != 0;
     const uint64_t env = (uint64_t)(env_id0 + i);
-    SpAgent a = sp_agent_half<NW, CN, CK>(g, e, actions[i], pend, side, forced_side, seed, step, env, i, err);
+    SpAgent a = sp_agent_half<NW, CN, CK>(g, e, actions[i], pend, side, forced_side, seed, step, env, i, err,
+                                          (flags & MNK_STEP_STRICT) != 0);
     if (a.need_opp) {
       const int oa = env_pick_legal<NW, CN>(g, e, mnk_rand_u32(seed, env, step, MNK_STREAM_OPP));
       const MnkPly ply = env_play<NW, CN, CK, true>(g, e, oa, false);
@@ -354,128 +356,6 @@ k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, c
     if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, NT);
   }
   if (ep.stats) mnk_ep_flush(ep, lds_ep);
-}
-
-// ------------------------------------------------------------------ masked categorical head + draw
-// alg/architectures/cnn.py:69-79 fused with Categorical.sample (policy.py:46-52).  One wave per
-// row: lanes stride over the C cells, a butterfly (shuffle-xor) argmax picks the winner of the
-// reductions over one 32-lane half of the wave (a row of logits lives in one half)
-__device__ __forceinline__ void half_argmax(float& v, int& idx) {
-#pragma unroll
-  for (int off = 16; off > 0; off >>= 1) {
-    const float ov = __shfl_xor(v, off, 64);
-    const int oi = __shfl_xor(idx, off, 64);
-    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-  }
-}
-
-__device__ __forceinline__ float half_max(float v) {
-#pragma unroll
-  for (int off = 16; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
-}
-
-__device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-  for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
-// Two rows per wave (one per 32-lane half).  The draw is an inverse-CDF lookup, not a per-cell perturbation:
-// lane l of the half owns the K = ceil(C/32) consecutive cells [l*K, (l+1)*K), weights e^(logit - max) are
-// summed per lane, a 5-step shuffle scan gives every lane the weight in front of it, ONE Philox uniform per row
-// picks the point u * total on that axis, a ballot finds the lane that holds it and that lane walks its K
-// cells.  One exp per cell instead of one Philox block + two logs per four cells (Gumbel-max, measured first:
-// 44 us for 65 536 x 81).  Distribution = softmax over the legal cells (chi-square test); ties / rounding at the
-// very end of the axis fall on the last legal cell.
-// K = cells per lane is a template parameter (loops fully unrolled, all loads of a lane issued together
-// with clamped addresses: per-cell predicated loads serialised into ~16 memory round trips).
-#define SAMPLE_MAX_K 16  // boards up to 512 cells
-template <int K>
-__global__ void __launch_bounds__(64)
-k_sample_logits(const float* logits, const uint8_t* mask, int64_t N, int C, uint64_t seed, uint64_t step,
-                const uint64_t* step_dev, int64_t env_id0, int deterministic, int64_t* actions, float* logp) {
-  const int lane = threadIdx.x, half = lane >> 5, sub = lane & 31;
-  if (step_dev) step += *step_dev;
-  const int64_t row = (int64_t)blockIdx.x * 2 + half;
-  const bool live = row < N;
-  const int64_t i = live ? row : N - 1;
-  const float* lrow = logits + i * C;
-  const uint8_t* mrow = mask + i * C;
-  const float NEG = -__builtin_huge_valf();
-  const int c_lo = sub * K;
-  // this lane's cells: logit and legality (addresses clamped into the row, validity applied afterwards)
-  float raw[K];
-  uint8_t ok[K];
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    const int c = min(c_lo + j, C - 1);
-    raw[j] = lrow[c];
-    ok[j] = mrow[c];
-  }
-  float l[K];
-  int any = 0;
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    const bool legal = (c_lo + j < C) && ok[j] != 0;
-    any |= legal ? 1 : 0;
-    l[j] = legal ? raw[j] : NEG;
-  }
-  // does the row have a legal cell at all?  (cnn.py:76-77: all-masked -> zeros -> uniform over all cells)
-  const unsigned long long votes = __ballot(any != 0);
-  const bool none_legal = ((uint32_t)(votes >> (32 * half))) == 0u;
-#pragma unroll
-  for (int j = 0; j < K; ++j) l[j] = none_legal ? ((c_lo + j < C) ? 0.0f : NEG) : l[j];
-  float vmax = NEG;
-  int amax = 0x7fffffff;
-#pragma unroll
-  for (int j = 0; j < K; ++j)
-    if (l[j] > vmax) { vmax = l[j]; amax = c_lo + j; }  // first maximum of the lane, cells ascend
-  float rowmax = vmax;
-  int rowarg = amax;
-  half_argmax(rowmax, rowarg);  // ties -> lowest cell, like torch.argmax (policy.py:48-49)
-  float w[K];
-  float mine = 0.0f;
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    w[j] = (l[j] == NEG) ? 0.0f : __expf(l[j] - rowmax);
-    mine += w[j];
-  }
-  // inclusive scan over the 32 lanes of the half
-  float incl = mine;
-#pragma unroll
-  for (int off = 1; off < 32; off <<= 1) {
-    const float up = __shfl_up(incl, off, 32);
-    if (sub >= off) incl += up;
-  }
-  const float total = __shfl(incl, 31, 32);
-  int chosen = rowarg;
-  if (!deterministic) {
-    const uint32_t x = mnk_rand_u32(seed, (uint64_t)(env_id0 + i), step, MNK_STREAM_SAMPLE);
-    const float u = ((float)(x >> 8) + 0.5f) * 5.9604644775390625e-08f;  // (0,1)
-    const float target = u * total;
-    // first lane whose inclusive sum passes the target (the last lane with weight, if rounding overshoots)
-    const unsigned long long pass = __ballot(incl > target && mine > 0.0f);
-    const unsigned long long heavy = __ballot(mine > 0.0f);
-    const uint32_t pass_h = (uint32_t)(pass >> (32 * half)), heavy_h = (uint32_t)(heavy >> (32 * half));
-    const int owner = pass_h ? __ffs(pass_h) - 1 : 31 - __clz(heavy_h);
-    // every lane walks its own cells (no divergence); the owner's answer is broadcast
-    float run = incl - mine;
-    int pick = 0x7fffffff, last = c_lo;
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-      run += w[j];
-      const bool has = w[j] > 0.0f;
-      last = has ? c_lo + j : last;
-      pick = (has && pick == 0x7fffffff && run > target) ? c_lo + j : pick;
-    }
-    pick = pick == 0x7fffffff ? last : pick;
-    chosen = __shfl(pick, owner, 32);
-  }
-  if (sub == 0 && live) {
-    actions[row] = chosen;
-    if (logp) logp[row] = (none_legal ? 0.0f : lrow[chosen]) - rowmax - logf(total);
-  }
 }
 
 // ------------------------------------------------------------------ records -> RolloutBuffer layout
@@ -738,7 +618,7 @@ int mnk_sample_legal(const uint64_t* planes, int64_t N, int m, int n, uint64_t s
 int mnk_selfplay_pre(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const int64_t* actions,
                      const uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
                      uint64_t step, const uint64_t* step_dev, int64_t env_id0, float* rewards, uint8_t* terminated,
-                     uint8_t* sp_flags, float* opp_obs, uint8_t* opp_mask, int32_t* err, void* stream) {
+                     uint8_t* sp_flags, float* opp_obs, uint8_t* opp_mask, int32_t* err, uint32_t flags, void* stream) {
   MnkGeom g;
   int rc = mnk_check_geom(m, n, k, &g);
   if (rc != MNK_OK) return rc;
@@ -752,14 +632,14 @@ int mnk_selfplay_pre(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, 
   const dim3 grid((unsigned)((N + B - 1) / B));
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_pre), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, planes, meta,
                                          N, actions, pending, agent_side, forced_side, seed, step, step_dev, env_id0,
-                                         rewards, terminated, sp_flags, opp_obs, opp_mask, err, vec_ok, B));
+                                         rewards, terminated, sp_flags, opp_obs, opp_mask, err, flags, vec_ok, B));
   return mnk_launch_status("selfplay_pre");
 }
 
 int mnk_selfplay_post(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const int64_t* opp_actions,
                       const uint8_t* sp_flags, const int64_t* agent_side, float* rewards, uint8_t* terminated,
                       uint8_t* pending, float* obs, uint8_t* legal_mask, int32_t* err, float* ep_return,
-                      int32_t* ep_length, int64_t* ep_stats, void* stream) {
+                      int32_t* ep_length, int64_t* ep_stats, uint32_t flags, void* stream) {
   MnkGeom g;
   int rc = mnk_check_geom(m, n, k, &g);
   if (rc != MNK_OK) return rc;
@@ -775,7 +655,7 @@ int mnk_selfplay_post(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n,
   const dim3 grid((unsigned)((N + B - 1) / B));
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_post), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, planes,
                                          meta, N, opp_actions, sp_flags, agent_side, rewards, terminated, pending, obs,
-                                         legal_mask, err, ep, vec_ok, B));
+                                         legal_mask, err, ep, flags, vec_ok, B));
   return mnk_launch_status("selfplay_post");
 }
 
@@ -783,7 +663,7 @@ int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m,
                              uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
                              uint64_t step, const uint64_t* step_dev, int64_t env_id0, float* rewards,
                              uint8_t* terminated, float* obs, uint8_t* legal_mask, int32_t* err, float* ep_return,
-                             int32_t* ep_length, int64_t* ep_stats, void* stream) {
+                             int32_t* ep_length, int64_t* ep_stats, uint32_t flags, void* stream) {
   MnkGeom g;
   int rc = mnk_check_geom(m, n, k, &g);
   if (rc != MNK_OK) return rc;
@@ -798,32 +678,8 @@ int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m,
   const dim3 grid((unsigned)((N + B - 1) / B));
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_step_random), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g,
                                          planes, meta, N, actions, pending, agent_side, forced_side, seed, step,
-                                         step_dev, env_id0, rewards, terminated, obs, legal_mask, err, ep, vec_ok, B));
+                                         step_dev, env_id0, rewards, terminated, obs, legal_mask, err, ep, flags, vec_ok, B));
   return mnk_launch_status("selfplay_step_random");
-}
-
-int mnk_sample_logits(const float* logits, const uint8_t* mask, int64_t N, int C, uint64_t seed, uint64_t step,
-                      const uint64_t* step_dev, int64_t env_id0, int deterministic, int64_t* actions, float* logp,
-                      void* stream) {
-  if (!logits || !mask || !actions || N < 0 || C < 1 || C > 32 * SAMPLE_MAX_K) return MNK_EINVAL;
-  if (N == 0) return MNK_OK;
-  if (N > 0x7fffffffLL) return MNK_EINVAL;
-  const dim3 grid((unsigned)((N + 1) / 2));
-#define MNK_SAMPLE(KV)                                                                                             \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sample_logits<KV>), grid, dim3(64), 0, (hipStream_t)stream, logits, mask, N, \
-                     C, seed, step, step_dev, env_id0, deterministic, actions, logp)
-  switch ((C + 31) / 32) {  // cells per lane
-    case 1: MNK_SAMPLE(1); break;
-    case 2: MNK_SAMPLE(2); break;
-    case 3: MNK_SAMPLE(3); break;   // 9x9
-    case 4: MNK_SAMPLE(4); break;
-    case 5: case 6: MNK_SAMPLE(6); break;   // 13x13
-    case 7: case 8: MNK_SAMPLE(8); break;   // 15x15
-    case 9: case 10: case 11: case 12: MNK_SAMPLE(12); break;   // 19x19
-    default: MNK_SAMPLE(16); break;
-  }
-#undef MNK_SAMPLE
-  return mnk_launch_status("sample_logits");
 }
 
 int mnk_unpack_records(const uint64_t* rec_planes, const uint32_t* rec_meta, int64_t N, int T, int m, int n,

@@ -11,11 +11,13 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmnk_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 MNK_OK = 0
 ERR_NONE, ERR_ACTION_RANGE, ERR_ILLEGAL_MOVE = 0, 1, 2
 STEP_STRICT = 1
+LOGITS_F32, LOGITS_BF16 = 0, 1
+COMM_ID_BYTES = 128
 SP_NEED_OPP, SP_WAS_RESET = 1, 2
 STREAM_MOVE, STREAM_OPP, STREAM_SIDE, STREAM_SAMPLE = 0, 1, 2, 3
 STATS_REPLICAS, STATS_STRIDE, STATS_COUNTERS = 64, 8, 5
@@ -40,22 +42,28 @@ SIGNATURES = {
     "mnk_pack_boards": [_vp, _vp, _i64, _i, _i, _vp],
     "mnk_unpack_boards": [_vp, _vp, _i64, _i, _i, _vp],
     "mnk_sample_legal": [_vp, _i64, _i, _i, _u64, _u64, _vp, _i64, _i, _vp, _vp],
-    "mnk_sample_logits": [_vp, _vp, _i64, _i, _u64, _u64, _vp, _i64, _i, _vp, _vp, _vp],
+    "mnk_sample_logits": [_vp, _i, _vp, _i64, _i, _u64, _u64, _vp, _i64, _i, _vp, _vp, _vp],
     "mnk_selfplay_pre": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _vp, _vp, _vp,
-                         _vp, _vp, _vp],
+                         _vp, _vp, _u32, _vp],
     "mnk_selfplay_post": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                          _vp],
+                          _u32, _vp],
     "mnk_selfplay_step_random": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _vp,
-                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+                                 _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     "mnk_rollout_random": [_vp, _vp, _i64, _i, _i, _i, _i, _u64, _u64, _i64, _vp, _vp, _vp, _vp, _i, _vp],
     "mnk_replay_actions": [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "mnk_unpack_records": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "mnk_gather_obs": [_vp, _i64, _i64, _i, _i, _vp, _i64, _vp, _vp, _i, _vp, _vp],
     "mnk_gae": [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp],
+    "mnk_comm_unique_id": [_vp],
+    "mnk_comm_init": [_vp, _vp, _i, _i],
+    "mnk_comm_destroy": [_vp],
+    "mnk_allgather_records": [_vp, _vp, _vp, _i64, _vp],
+    "mnk_comm_last_error": [],
+    "mnk_comm_version": [],
 }
 
 _STATUS = {-1: "invalid argument (null pointer / negative size)", -2: "unsupported board geometry",
-           -3: "kernel launch failed"}
+           -3: "kernel launch failed", -4: "RCCL call failed"}
 
 
 class MnkHipError(RuntimeError):
@@ -79,7 +87,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header / library mismatch
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_char_p if name == "mnk_last_launch_error" else ctypes.c_int
+        fn.restype = ctypes.c_char_p if name in ("mnk_last_launch_error", "mnk_comm_last_error") else ctypes.c_int
     if lib.mnk_abi_version() != ABI_VERSION:
         raise MnkHipError(f"libmnk_hip.so ABI {lib.mnk_abi_version()} != binding ABI {ABI_VERSION}")
     _lib = lib
@@ -111,6 +119,8 @@ def call(name, *args):
         detail = _STATUS.get(rc, f"status {rc}")
         if rc == -3:
             detail += ": " + (lib.mnk_last_launch_error() or b"").decode()
+        if rc == -4:
+            detail += ": " + (lib.mnk_comm_last_error() or b"").decode()
         raise MnkHipError(f"{name}: {detail}")
     return rc
 

@@ -31,7 +31,9 @@ class GraphedAgentStep:
     def __init__(self, wrapper, net, seed=None):
         self.wrapper, self.net = wrapper, net
         self.dev = wrapper._dev
-        self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        from selfplay.policy import default_key
+
+        self.seed = default_key(seed)  # unseeded: a key of its own, never the opponent sampler's
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)
         obs, _ = wrapper.reset()
         self.cur_obs = obs["observation"].clone()
@@ -47,10 +49,14 @@ class GraphedAgentStep:
         prev_obs, prev_mask = self.cur_obs.clone(), self.cur_mask.clone()
         with torch.no_grad():
             dist, values = self.net(self.cur_obs, None)
-            logits = dist.logits.to(torch.float32).contiguous()
+            logits = dist.logits.contiguous()
+            if logits.dtype not in (torch.float32, torch.bfloat16):
+                logits = logits.to(torch.float32)
         actions = torch.empty(n, dtype=torch.long, device=self.dev)
         logp = torch.empty(n, dtype=torch.float32, device=self.dev)
-        mnk_hip.call("mnk_sample_logits", mnk_hip.ptr(logits), mnk_hip.ptr(self.cur_mask), n, logits.shape[1],
+        mnk_hip.call("mnk_sample_logits", mnk_hip.ptr(logits),
+                     mnk_hip.LOGITS_BF16 if logits.dtype == torch.bfloat16 else mnk_hip.LOGITS_F32,
+                     mnk_hip.ptr(self.cur_mask), n, logits.shape[1],
                      self.seed, 0, mnk_hip.ptr(self.step_dev), w.env_id0, 0, mnk_hip.ptr(actions), mnk_hip.ptr(logp),
                      mnk_hip.stream_ptr(self.dev))
         nxt, rewards, term, trunc, _ = w._advance(actions, w._forced_sides)

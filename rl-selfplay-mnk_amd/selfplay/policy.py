@@ -24,27 +24,61 @@ class Policy(ABC):
         pass
 
 
+_GOLDEN = 0x9E3779B97F4A7C15
+_instances = [0]  # samplers created so far in this process
+
+
+def _mix64(x: int) -> int:
+    """splitmix64 finaliser: a bijection on 64-bit integers with good avalanche"""
+    x &= 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return x ^ (x >> 31)
+
+
+def default_key(seed=None) -> int:
+    """Philox key of a sampler.  With an explicit ``seed`` the key IS the seed (reproducible, what the tests use).
+    Without one -- the reference's constructors take no seed (policy.py:14, :33) -- every sampler created in the
+    process gets its own key, derived from ``torch.initial_seed()`` and a per-process instance counter: two
+    unseeded policies (agent and opponent of the same net, two RandomPolicy instances) must not draw the same
+    uniform for row i on call c.  ``torch.manual_seed`` before constructing the policies makes a run repeatable."""
+    if seed is not None:
+        return int(seed) & 0xFFFFFFFFFFFFFFFF
+    _instances[0] += 1
+    return _mix64(int(torch.initial_seed()) + _instances[0] * _GOLDEN)
+
+
 class _HipSampler:
     """Philox-keyed draws from masked logits on the mask's device."""
 
     def __init__(self, seed=None):
-        self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        self.seed = default_key(seed)
         self.calls = 0
         self.step_dev = None  # optional device int64[1] added to the step counter (graph replays)
 
     def draw(self, logits, mask, deterministic, want_logp=False):
+        """logits: f32 / bf16 [B, C] (bf16 is read as is -- what a network emits under autocast, alg/ppo.py:194),
+        or None for all-zero logits (a uniform draw over the legal cells that reads only the mask)."""
         mask = mask.contiguous()
         if mask.device.type != "cuda":
             raise RuntimeError("mnk policies sample on the GPU; got a mask on " + str(mask.device))
         if mask.dim() == 1:
             mask = mask.unsqueeze(0)
+        if mask.dtype != torch.bool and mask.dtype != torch.uint8:
+            mask = mask != 0
         b, c = mask.shape
-        logits = logits.to(torch.float32).reshape(b, c).contiguous()
+        dtype = mnk_hip.LOGITS_F32
+        if logits is not None:
+            if logits.dtype == torch.bfloat16:
+                dtype = mnk_hip.LOGITS_BF16
+            elif logits.dtype != torch.float32:
+                logits = logits.to(torch.float32)
+            logits = logits.reshape(b, c).contiguous()
         actions = torch.empty(b, dtype=torch.long, device=mask.device)
         logp = torch.empty(b, dtype=torch.float32, device=mask.device) if want_logp else None
         if b:
-            mnk_hip.call("mnk_sample_logits", mnk_hip.ptr(logits), mnk_hip.ptr(mask), b, c, self.seed, self.calls,
-                         mnk_hip.ptr(self.step_dev), 0, 1 if deterministic else 0, mnk_hip.ptr(actions),
+            mnk_hip.call("mnk_sample_logits", mnk_hip.ptr(logits), dtype, mnk_hip.ptr(mask), b, c, self.seed,
+                         self.calls, mnk_hip.ptr(self.step_dev), 0, 1 if deterministic else 0, mnk_hip.ptr(actions),
                          mnk_hip.ptr(logp), mnk_hip.stream_ptr(mask.device))
         if self.step_dev is None:
             self.calls += 1
@@ -57,16 +91,11 @@ class RandomPolicy(Policy):
     def __init__(self, action_dim: int, seed=None):
         self.action_dim = action_dim
         self._sampler = _HipSampler(seed)
-        self._zeros = None
 
     def act(self, obs: Dict[str, torch.Tensor], deterministic: bool = False) -> torch.Tensor:
-        mask = obs["action_mask"]
-        if mask.dim() == 1:
-            mask = mask.unsqueeze(0)
-        if self._zeros is None or self._zeros.shape != mask.shape or self._zeros.device != mask.device:
-            self._zeros = torch.zeros(mask.shape, dtype=torch.float32, device=mask.device)
-        # deterministic: argmax of the 0/1 weights = first legal cell (policy.py:26-27)
-        return self._sampler.draw(self._zeros, mask, deterministic)
+        # all logits zero: uniform over the legal cells; deterministic: argmax of the 0/1 weights = first legal
+        # cell (policy.py:26-27).  No logits tensor is materialised -- the kernel reads the mask only.
+        return self._sampler.draw(None, obs["action_mask"], deterministic)
 
 
 class NNPolicy(Policy):

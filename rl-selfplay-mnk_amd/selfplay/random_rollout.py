@@ -172,20 +172,31 @@ class GatheredLogs:
         return GatheredLogs(planes0=planes0, meta0=meta0, act=act, steps=steps, msg=msg)
 
 
-def gather_action_logs(rec: RolloutRecords, group=None, out: Optional[GatheredLogs] = None) -> GatheredLogs:
+def gather_action_logs(rec: RolloutRecords, group=None, out: Optional[GatheredLogs] = None, exchange=None,
+                       stream=None) -> GatheredLogs:
     """All-gather of (chunk-start state, action log) as ONE message per rank: 1-2 bytes per env-step on the
-    wire plus the 36 B/env state once per chunk."""
-    import torch.distributed as dist
+    wire plus the 36 B/env state once per chunk.
 
+    ``exchange``: a ``selfplay.exchange.RecordExchange`` -- the collective is then ``mnk_allgather_records`` of
+    the C ABI (RCCL over xGMI) enqueued on ``stream`` (default: the current stream).  Without it the
+    ``torch.distributed`` group is used (``gloo`` in the CPU tests, ``nccl`` = the same RCCL otherwise)."""
     assert rec.msg is not None, "run the rollout with alloc(..., log_actions=True)"
-    world = dist.get_world_size(group)
+    if exchange is not None:
+        world = exchange.world
+    else:
+        import torch.distributed as dist
+
+        world = dist.get_world_size(group)
     t, n = rec.meta.shape
     w = rec.planes0.shape[1]  # the chunk-start state travels in the state layout [2, W, N]
     num_actions = 256 if rec.act.dtype == torch.int32 else 65536
     if out is None:
         out = GatheredLogs.empty(world, w, n, t, num_actions, rec.msg.device)
     assert out.msg.shape == (world, rec.msg.numel()) and out.steps == t
-    dist.all_gather_into_tensor(out.msg.view(-1), rec.msg, group=group)
+    if exchange is not None:
+        exchange.all_gather(rec.msg, out.msg.view(-1), stream)
+    else:
+        dist.all_gather_into_tensor(out.msg.view(-1), rec.msg, group=group)
     return out
 
 
@@ -262,9 +273,15 @@ def gae(rewards, values, dones, last_values, gamma: float = 0.99, gae_lambda: fl
     dev = rewards.device
     adv = torch.empty((t, n), dtype=torch.float32, device=dev)
     ret = torch.empty((t, n), dtype=torch.float32, device=dev)
+    # the contiguous copies are bound to names: a temporary would be freed (and its block reused by the next
+    # temporary) before the launch has read it
+    r = rewards.to(torch.float32).contiguous()
+    v = values.to(torch.float32).contiguous()
+    d = dones.to(torch.bool).contiguous()
+    last = last_values.to(torch.float32).reshape(-1).contiguous()
+    assert v.shape == (t, n) and d.shape == (t, n) and last.numel() == n
     if t and n:
-        mnk_hip.call("mnk_gae", mnk_hip.ptr(rewards.contiguous()), mnk_hip.ptr(values.contiguous()),
-                     mnk_hip.ptr(dones.contiguous()), mnk_hip.ptr(last_values.reshape(-1).contiguous()), n, t,
+        mnk_hip.call("mnk_gae", mnk_hip.ptr(r), mnk_hip.ptr(v), mnk_hip.ptr(d), mnk_hip.ptr(last), n, t,
                      float(gamma), float(gamma * gae_lambda), mnk_hip.ptr(adv), mnk_hip.ptr(ret),
                      mnk_hip.stream_ptr(dev))
     return adv, ret

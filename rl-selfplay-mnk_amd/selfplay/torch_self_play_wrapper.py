@@ -45,7 +45,9 @@ class TorchSelfPlayWrapper:
         self.agent_side = torch.zeros(self.num_envs, dtype=torch.long, device=self._dev)
         self.pending_resets = torch.zeros(self.num_envs, dtype=torch.bool, device=self._dev)
 
-        self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        from selfplay.policy import default_key
+
+        self.seed = default_key(seed)  # side draws and the built-in random opponent: streams SIDE / OPP of this key
         self.env_id0 = 0          # global id of env 0 (rank * num_envs when the env axis is sharded)
         self.step_count = 0       # Philox step counter: one per reset()/step() call
         self._forced_sides = None
@@ -60,11 +62,17 @@ class TorchSelfPlayWrapper:
     def force_sides(self, sides) -> None:
         """Sides to hand out at the next (auto)reset instead of the Philox draw: an int, an
         (N,) tensor, or None to go back to drawing.  Only envs that actually reset read it."""
-        if sides is None:
-            self._forced_sides = None
-        else:
-            t = torch.as_tensor(sides, device=self._dev).to(torch.long)
-            self._forced_sides = t.expand(self.num_envs).contiguous() if t.dim() == 0 else t.contiguous()
+        self._forced_sides = None if sides is None else self._side_tensor(sides)
+
+    def _side_tensor(self, sides) -> torch.Tensor:
+        """int or (N,) -> contiguous int64 [N]; the kernels read element i for every env i < N"""
+        t = torch.as_tensor(sides, device=self._dev).to(torch.long)
+        if t.dim() == 0:
+            return t.expand(self.num_envs).contiguous()
+        t = t.reshape(-1).contiguous()
+        if t.numel() != self.num_envs:
+            raise IndexError(f"shape mismatch: {t.numel()} sides for {self.num_envs} envs")
+        return t
 
     # ------------------------------------------------------------------ device-side episode statistics
     def track_episodes(self, on: bool = True) -> None:
@@ -80,9 +88,12 @@ class TorchSelfPlayWrapper:
             self._ep_return = self._ep_length = self._ep_stats = None
 
     def pop_episode_stats(self) -> dict:
-        """Episodes finished since the last call (one host synchronisation): counts, mean reward, mean length."""
+        """Episodes finished since the last call (one host synchronisation): counts, mean reward, mean length.
+        Also the place where a device-side error recorded by an earlier step (an action outside [-C, C): the
+        env is left untouched and would stall) surfaces as an exception on non-strict envs."""
         if self._ep_stats is None:
             raise RuntimeError("call track_episodes() first")
+        self.env.check_errors()
         episodes, wins, losses, draws, length = self._ep_stats.sum(dim=0)[:mnk_hip.STATS_COUNTERS].tolist()
         self._ep_stats.zero_()
         return {"episodes": episodes, "wins": wins, "losses": losses, "draws": draws,
@@ -96,8 +107,7 @@ class TorchSelfPlayWrapper:
             self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         forced = self._forced_sides
         if options and "agent_side" in options:
-            t = torch.as_tensor(options["agent_side"], device=self._dev).to(torch.long)
-            forced = t.expand(self.num_envs).contiguous() if t.dim() == 0 else t.contiguous()
+            forced = self._side_tensor(options["agent_side"])
         # a reset is a step in which every env is pending: boards cleared, sides handed out,
         # the opponent opens wherever the agent is white, and its outcome is ignored (:28)
         self.pending_resets.fill_(True)
@@ -155,7 +165,7 @@ class TorchSelfPlayWrapper:
                          mnk_hip.ptr(self.step_dev), self.env_id0,
                          mnk_hip.ptr(rewards), mnk_hip.ptr(terminated), mnk_hip.ptr(obs), mnk_hip.ptr(mask),
                          mnk_hip.ptr(env._err), mnk_hip.ptr(self._ep_return), mnk_hip.ptr(self._ep_length),
-                         mnk_hip.ptr(self._ep_stats), env._stream())
+                         mnk_hip.ptr(self._ep_stats), env._flags(), env._stream())
         else:
             if opp is None:
                 raise RuntimeError("TorchSelfPlayWrapper: set_opponent(policy) before reset()/step()")
@@ -166,7 +176,7 @@ class TorchSelfPlayWrapper:
                          mnk_hip.ptr(forced), self.seed, step, mnk_hip.ptr(self.step_dev), self.env_id0,
                          mnk_hip.ptr(rewards),
                          mnk_hip.ptr(terminated), mnk_hip.ptr(self._flags), mnk_hip.ptr(opp_obs),
-                         mnk_hip.ptr(opp_mask), mnk_hip.ptr(env._err), env._stream())
+                         mnk_hip.ptr(opp_mask), mnk_hip.ptr(env._err), env._flags(), env._stream())
             with torch.no_grad():  # wrapper:91-94: one positional argument, no `deterministic`
                 opp_actions = opp.act({"observation": opp_obs, "action_mask": opp_mask})
             opp_actions = torch.as_tensor(opp_actions, device=dev).to(torch.long).reshape(-1).contiguous()
@@ -176,7 +186,7 @@ class TorchSelfPlayWrapper:
                          env.k, mnk_hip.ptr(opp_actions), mnk_hip.ptr(self._flags), mnk_hip.ptr(self.agent_side),
                          mnk_hip.ptr(rewards), mnk_hip.ptr(terminated), mnk_hip.ptr(self.pending_resets),
                          mnk_hip.ptr(obs), mnk_hip.ptr(mask), mnk_hip.ptr(env._err), mnk_hip.ptr(self._ep_return),
-                         mnk_hip.ptr(self._ep_length), mnk_hip.ptr(self._ep_stats), env._stream())
+                         mnk_hip.ptr(self._ep_length), mnk_hip.ptr(self._ep_stats), env._flags(), env._stream())
         if env.strict:
             env.check_errors()
         return {"observation": obs, "action_mask": mask}, rewards, terminated, torch.zeros_like(terminated), {}

@@ -119,3 +119,55 @@ def play_scenario(env, sc):
                       int(env.move_counts[0])]).astype(np.int8),
         ]))
     return np.stack(rows)
+
+
+def replay_ppo_learn(wrapper, make_buffer, log, set_sides, episode_stats=None):
+    """Replays tests/golden/ppo_learn_*.npz: the call sequence of the reference's ``PPOAgent.learn`` rollout
+    (alg/ppo.py:81-136 -- reset once, then per step: take obs/mask, step with the action the reference's network
+    sampled, ``buffer.add(obs, action, reward, value, log_prob, done, mask)``, keep the new obs across ``learn``
+    calls; after n_steps: ``compute_advantages_and_returns(last_values)``) on ``wrapper`` + ``make_buffer(...)``,
+    and compares every buffer field with what the reference's buffer held, bit for bit.
+
+    ``episode_stats()`` (optional) returns {"mean_reward", "mean_length"} of the episodes finished since its last
+    call -- compared with the ``TrainingMetrics`` the reference's ``learn`` returned (ppo.py:110-120, :150-151).
+    """
+    m, n, k, nenv, n_steps = (int(v) for v in log["geom"])
+    gamma, lam = (float(v) for v in log["hyper"])
+    dev = wrapper.device
+    calls = log["actions"].shape[0] // n_steps
+    set_sides(wrapper, log["sides"][0])
+    obs, info = wrapper.reset()
+    assert info == {}
+    for call in range(calls):
+        buf = make_buffer(n_steps, nenv, (2, m, n), m * n)
+        pre = f"call{call}/"
+        values = torch.from_numpy(log[pre + "values"]).to(dev)
+        log_probs = torch.from_numpy(log[pre + "log_probs"]).to(dev)
+        for t in range(n_steps):
+            g = call * n_steps + t
+            observation, action_mask = obs["observation"], obs["action_mask"]
+            actions = torch.from_numpy(log["actions"][g].astype(np.int64)).to(dev)
+            set_sides(wrapper, log["sides"][g + 1])
+            next_obs, rewards, terminateds, truncateds, _ = wrapper.step(actions)
+            dones = terminateds | truncateds
+            buf.add(observation, actions, rewards, values[t].view(-1, 1), log_probs[t], dones, action_mask)
+            obs = next_obs
+        assert buf.ptr == n_steps
+        buf.compute_advantages_and_returns(torch.from_numpy(log[pre + "last_values"]).to(dev), gamma, lam)
+        where = f"learn call {call}"
+        got_planes = np.stack([pack_boards(_np(o), m, n) for o in buf.observations])
+        got_mask = np.stack([pack_cells(_np(a), m, n) for a in buf.action_masks])
+        assert np.array_equal(got_planes, log[pre + "obs_planes"]), f"{where}: observations"
+        assert np.array_equal(got_mask, log[pre + "obs_mask"]), f"{where}: action_masks"
+        assert np.array_equal(_np(buf.actions).astype(np.int32), log[pre + "actions"]), f"{where}: actions"
+        assert np.array_equal(_np(buf.rewards), log[pre + "rewards"].astype(np.float32)), f"{where}: rewards"
+        assert np.array_equal(_np(buf.dones), log[pre + "dones"]), f"{where}: dones"
+        assert np.array_equal(_np(buf.values), log[pre + "values"]), f"{where}: values"
+        assert np.array_equal(_np(buf.log_probs), log[pre + "log_probs"]), f"{where}: log_probs"
+        assert np.array_equal(_np(buf.advantages), log[pre + "advantages"]), f"{where}: advantages"
+        assert np.array_equal(_np(buf.returns), log[pre + "returns"]), f"{where}: returns"
+        if episode_stats is not None:
+            st = episode_stats()
+            want_reward, want_length = (float(v) for v in log[pre + "metrics"])
+            assert abs(st["mean_reward"] - want_reward) < 1e-9, f"{where}: mean_reward"
+            assert abs(st["mean_length"] - want_length) < 1e-9, f"{where}: mean_length"

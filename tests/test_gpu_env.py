@@ -1,5 +1,7 @@
 """GPU parity: the HIP env (through the C ABI) against the golden vectors of the
 reference and against the oracle.  Bit-exact everywhere (integer / byte work)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -392,3 +394,35 @@ def test_rollout_soak_is_deterministic(hip):
     assert abs(length / episodes - 53.56) < 0.06
     assert abs(draws / episodes - 0.0029) < 0.0003
     assert 0.50 < black / (black + white) < 0.54  # the first-move advantage of random play
+
+
+def test_oversized_emit_threads_setting_is_refused_not_launched():
+    """Round-1 fault: MNK_EMIT_THREADS=512 launched 512 threads into __launch_bounds__(256) kernels
+    ("unspecified launch failure").  mnk_block_threads() now falls back to 256 for anything but 64/128/256; the
+    value is cached per process, so the check runs in a fresh child process: observe + step on a small env must
+    equal the oracle with the bad setting in the environment."""
+    import subprocess
+    import sys
+
+    child = r"""
+import os, sys
+sys.path[:0] = [%(root)r, os.path.join(%(root)r, "rl-selfplay-mnk_amd"), os.path.join(%(root)r, "tests")]
+import numpy as np, torch
+from env.torch_vector_mnk_env import TorchVectorMnkEnv
+from oracle.env_torch import OracleVectorEnv
+env, ora = TorchVectorMnkEnv(9, 9, 5, 200, device="cuda:0"), OracleVectorEnv(9, 9, 5, 200)
+rng = np.random.default_rng(0)
+for t in range(6):
+    a = torch.from_numpy(rng.integers(0, 81, 200))
+    o1, r1, d1 = env.step(a.to("cuda:0"))
+    o2, r2, d2 = ora.step(a)
+    assert torch.equal(o1["observation"].cpu(), o2["observation"]) and torch.equal(o1["action_mask"].cpu(), o2["action_mask"])
+    assert torch.equal(r1.cpu(), r2) and torch.equal(d1.cpu(), d2)
+o1, o2 = env.observe(), ora.observe()
+assert torch.equal(o1["observation"].cpu(), o2["observation"])
+torch.cuda.synchronize()
+print("EMIT_OK")
+""" % {"root": os.path.dirname(os.path.dirname(os.path.abspath(__file__)))}
+    env = dict(os.environ, MNK_EMIT_THREADS="512", MNK_EMIT_ENVS="48")
+    out = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=300)
+    assert "EMIT_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

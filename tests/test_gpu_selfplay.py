@@ -686,3 +686,141 @@ def test_graphed_agent_step_equals_eager(hip, opponent):
             assert torch.equal(out["actions"], actions) and torch.equal(out["rewards"], rew), t
             assert torch.equal(out["terminated"], term) and torch.allclose(out["log_probs"], logp), t
     assert torch.equal(graphed.current_obs()["observation"], obs["observation"])
+
+
+# ----------------------------------------------------------------------------- round-2 additions
+def test_unseeded_policies_draw_independently(hip):
+    """Policies built with the reference's signatures (no seed: policy.py:14, :33) must not share a random
+    stream: two RandomPolicy instances on the same mask disagree, and so do an unseeded wrapper's side draws
+    from another's."""
+    c, rows = 81, 20000
+    mask = torch.ones(rows, c, dtype=torch.bool, device=DEV)
+    a, b = hip.policy.RandomPolicy(c), hip.policy.RandomPolicy(c)
+    assert a._sampler.seed != b._sampler.seed
+    xa, xb = a.act({"action_mask": mask}), b.act({"action_mask": mask})
+    same = float((xa == xb).float().mean())
+    assert abs(same - 1.0 / c) < 0.01, same          # independent uniform draws agree with probability 1/81
+    corr = float(torch.corrcoef(torch.stack([xa.float(), xb.float()]))[0, 1])
+    assert abs(corr) < 0.03, corr
+    # a second call of the same policy moves on as well
+    assert float((a.act({"action_mask": mask}) == xa).float().mean()) < 0.05
+    w1, w2 = hip.Wrapper(hip.Env(3, 3, 3, 4096, device=DEV)), hip.Wrapper(hip.Env(3, 3, 3, 4096, device=DEV))
+    for w in (w1, w2):
+        w.set_opponent(hip.policy.RandomPolicy(9))
+        w.reset()
+    agree = float((w1.agent_side == w2.agent_side).float().mean())
+    assert 0.4 < agree < 0.6, agree
+    # explicit seeds stay reproducible
+    p, q = hip.policy.RandomPolicy(c, seed=5), hip.policy.RandomPolicy(c, seed=5)
+    assert torch.equal(p.act({"action_mask": mask}), q.act({"action_mask": mask}))
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_strict_env_is_strict_through_the_wrapper(hip, fused):
+    """strict=True refuses occupied cells on the agent's ply inside wrapper.step as well (message of the
+    reference's _validate_moves, env/torch_vector_mnk_env.py:94-104); the offending env is left untouched."""
+    env = hip.Env(3, 3, 3, 4, device=DEV, strict=True)
+    wrap = hip.Wrapper(env, seed=1)
+    opp = hip.policy.RandomPolicy(9, seed=2) if fused else LowestLegalPolicy()
+    wrap.set_opponent(opp)
+    wrap.reset(options={"agent_side": 0})
+    obs, *_ = wrap.step(torch.tensor([4, 4, 4, 4], device=DEV))           # agent takes the centre, opponent replies
+    before = env.boards[...].clone()
+    with pytest.raises(ValueError, match="Illegal Move: Env 2 tried to play in occupied cell."):
+        acts = torch.argmax(obs["action_mask"].to(torch.uint8), dim=1)
+        acts[2] = 4                                                           # occupied
+        wrap.step(acts)
+    after = env.boards[...]
+    assert torch.equal(after[2], before[2])                                  # untouched
+    assert int(after[0].sum()) == int(before[0].sum()) + 2                   # the others played on
+    # a non-strict env accepts the same move like the reference does (both planes may end up set, env:67-69)
+    env2 = hip.Env(3, 3, 3, 4, device=DEV)
+    wrap2 = hip.Wrapper(env2, seed=1)
+    wrap2.set_opponent(hip.policy.RandomPolicy(9, seed=2) if fused else LowestLegalPolicy())
+    wrap2.reset(options={"agent_side": 0})
+    wrap2.step(torch.tensor([4, 4, 4, 4], device=DEV))
+    wrap2.step(torch.tensor([4, 4, 4, 4], device=DEV))
+    env2.check_errors()
+
+
+def test_forced_sides_must_cover_every_env(hip):
+    wrap = hip.Wrapper(hip.Env(3, 3, 3, 8, device=DEV), seed=1)
+    wrap.set_opponent(LowestLegalPolicy())
+    with pytest.raises(IndexError, match="3 sides for 8 envs"):
+        wrap.force_sides(torch.tensor([0, 1, 0]))
+    with pytest.raises(IndexError, match="sides for 8 envs"):
+        wrap.reset(options={"agent_side": torch.zeros(9, dtype=torch.long)})
+    wrap.reset(options={"agent_side": 1})
+    assert bool((wrap.agent_side == 1).all())
+
+
+def test_out_of_range_action_surfaces_at_pop_episode_stats(hip):
+    """non-strict env: an action outside [-C, C) leaves the env untouched and sets the sticky device word; the
+    periodic pop_episode_stats() (one sync anyway) raises it -- the reference raises an IndexError at once."""
+    wrap = hip.Wrapper(hip.Env(3, 3, 3, 4, device=DEV), seed=1)
+    wrap.set_opponent(hip.policy.RandomPolicy(9, seed=2))
+    wrap.track_episodes()
+    wrap.reset(options={"agent_side": 0})
+    wrap.step(torch.tensor([0, 1, 99, 2], device=DEV))
+    with pytest.raises(IndexError, match="index 2 is out of bounds"):
+        wrap.pop_episode_stats()
+
+
+def test_bf16_logits_are_sampled_without_an_f32_copy(hip, golden_dir):
+    """mnk_sample_logits(MNK_LOGITS_BF16): argmax and log-prob equal torch's masked Categorical on the same
+    bf16-rounded logits (f32 arithmetic on both sides, 1e-5), for the reference nets' raw logits
+    (cnn.py:69-80 under the autocast of ppo.py:194)."""
+    data = np.load(f"{golden_dir}/masked_logits.npz")
+    sampler = hip.policy._HipSampler(seed=4)
+    for arch in ("cnn_b_s", "resnet_b_s"):
+        raw = torch.from_numpy(data[arch + "_raw_logits"]).to(DEV).to(torch.bfloat16)
+        mask = torch.from_numpy(data[arch + "_mask"]).to(DEV)
+        act, logp = sampler.draw(raw, mask, True, want_logp=True)
+        ref_logits = torch.where(mask, raw.float(), torch.full_like(raw.float(), -torch.inf))
+        dead = ~mask.any(dim=1)
+        ref_logits[dead] = 0.0                                    # cnn.py:76-77
+        ref = torch.distributions.Categorical(logits=ref_logits)
+        assert torch.equal(act, torch.argmax(ref.logits, dim=1))
+        assert torch.allclose(logp, ref.log_prob(act), atol=1e-5, rtol=0)
+        # draws: legal, and their log-prob is the reference's
+        act, logp = sampler.draw(raw, mask, False, want_logp=True)
+        assert bool(mask[~dead].gather(1, act[~dead].unsqueeze(1)).all())
+        assert torch.allclose(logp, ref.log_prob(act), atol=1e-5, rtol=0)
+    # a strided / odd-offset view still works (the unaligned scalar path of the kernel)
+    big = torch.randn(1001, 83, device=DEV)
+    view, m = big[1:, 1:82], torch.rand(1000, 81, device=DEV) > 0.3
+    m[:, 0] = True
+    a1, l1 = sampler.draw(view, m, True, want_logp=True)
+    ref = torch.distributions.Categorical(logits=torch.where(m, view, torch.full_like(view, -torch.inf)))
+    assert torch.equal(a1, torch.argmax(ref.logits, dim=1)) and torch.allclose(l1, ref.log_prob(a1), atol=1e-5, rtol=0)
+
+
+@pytest.mark.parametrize("m,n", [(3, 3), (4, 6), (7, 9), (9, 9), (10, 10), (13, 13), (15, 15), (19, 19), (22, 22)])
+def test_sampler_all_row_widths(hip, m, n):
+    """every (lanes per row, cells per lane) variant of k_sample_logits, ragged last workgroup included: argmax,
+    log-prob and legality of the draws against torch's masked Categorical"""
+    c, rows = m * n, 1237
+    g = torch.Generator(device="cpu").manual_seed(c)
+    logits = (torch.randn(rows, c, generator=g) * 3).to(DEV)
+    mask = (torch.rand(rows, c, generator=g) > 0.4).to(DEV)
+    mask[5] = False                                              # an all-masked row
+    mask[7] = False
+    mask[7, c - 1] = True                                        # a single legal cell, the last one
+    sampler = hip.policy._HipSampler(seed=c)
+    ref_logits = torch.where(mask, logits, torch.full_like(logits, -torch.inf))
+    ref_logits[5] = 0.0
+    ref = torch.distributions.Categorical(logits=ref_logits)
+    act, logp = sampler.draw(logits, mask, True, want_logp=True)
+    assert torch.equal(act, torch.argmax(ref.logits, dim=1))
+    assert torch.allclose(logp, ref.log_prob(act), atol=1e-5, rtol=0)
+    act, logp = sampler.draw(logits, mask, False, want_logp=True)
+    legal = mask.clone()
+    legal[5] = True
+    assert bool(legal.gather(1, act.unsqueeze(1)).all()) and int(act[7]) == c - 1
+    assert torch.allclose(logp, ref.log_prob(act), atol=1e-5, rtol=0)
+    # uniform form (logits == NULL): legal, and the first legal cell when deterministic
+    act = sampler.draw(None, mask, False)
+    assert bool(legal.gather(1, act.unsqueeze(1)).all())
+    first = sampler.draw(None, mask, True)
+    want = torch.argmax(legal.to(torch.uint8), dim=1)
+    assert torch.equal(first, want)

@@ -67,6 +67,29 @@ again = replay_shard(logs, 0, 9, 9, 5)
 assert torch.equal(again.planes, rec.planes) and torch.equal(again.meta, rec.meta)
 assert full is rec
 t = torch.ones(4, device=dev); dist.all_reduce(t); assert float(t.sum()) == 4.0
+# the same exchange through the C ABI (mnk_comm_* / mnk_allgather_records): id from rank 0 over the process group,
+# communicator on this rank's device, all-gather enqueued on the side stream
+from selfplay.exchange import RecordExchange
+import mnk_hip
+assert mnk_hip.load().mnk_comm_version() >= 20000
+ex = RecordExchange.from_process_group()
+assert (ex.rank, ex.world) == (0, 1)
+roll.run(64, out=rec)
+done.record()
+with torch.cuda.stream(side):
+    side.wait_event(done)
+    logs2 = gather_action_logs(rec, exchange=ex, stream=side)
+torch.cuda.current_stream().wait_stream(side)
+assert torch.equal(logs2.msg[0], rec.msg)
+again = replay_shard(logs2, 0, 9, 9, 5)
+assert torch.equal(again.planes, rec.planes) and torch.equal(again.meta, rec.meta)
+try:
+    ex.all_gather(rec.msg, torch.empty(3, dtype=torch.int64, device=dev))
+    raise SystemExit("a short receive buffer was accepted")
+except ValueError:
+    pass
+torch.cuda.synchronize()
+ex.close()
 dist.barrier(); dist.destroy_process_group()
 print("NCCL_OK")
 """
@@ -74,7 +97,9 @@ print("NCCL_OK")
 
 def test_exchange_step_on_the_rccl_backend():
     """One rank, backend nccl (= RCCL): process-group init on the GPU, the all-gather of the action-log message
-    on a side stream, replay of the gathered shard.  (More ranks need more GPUs: the driver's multi-GPU run.)"""
+    on a side stream -- once through torch.distributed, once through the C ABI's own communicator
+    (mnk_comm_init / mnk_allgather_records) -- and replay of the gathered shard.  (More ranks need more GPUs:
+    the driver's multi-GPU run.)"""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
