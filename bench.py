@@ -60,7 +60,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(16, host cores): the CPU share of one GPU")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="0 = every CPU this process may use (affinity mask and cgroup quota)")
     ap.add_argument("--no-api-path", action="store_true", help="skip the extra per-step-launch measurement")
     ap.add_argument("--mode", choices=("rollout", "selfplay"), default="rollout",
                     help="rollout = the BASELINE.json metric (default); selfplay = BASELINE config 3: the wrapper loop "
@@ -84,6 +85,30 @@ def state_bytes(words):
     return 16 * words + 4
 
 
+def host_cpu_identity():
+    """CPU model, logical CPUs of the host, and the CPUs this process may actually use (affinity mask and
+    cgroup quota: a GPU box hands one GPU's job a share of the host, not all of it)."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+    try:  # cgroup v2 quota: "max 100000" or "<quota> <period>"
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+            if quota != "max":
+                usable = max(1, min(usable, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return model, logical, usable
+
+
 def cpu_baseline(env, seconds, threads=0):
     """The oracle's torch-eager restatement of the reference env (conv2d win scan) and of
     RandomPolicy (multinomial), timed on the host cores from the GPU env's current (stationary)
@@ -92,7 +117,8 @@ def cpu_baseline(env, seconds, threads=0):
     from oracle.policies import OracleRandomPolicy
 
     n = env.num_envs
-    threads = threads or min(16, os.cpu_count() or 1)
+    model, logical, usable = host_cpu_identity()
+    threads = threads or usable  # every core this process may use
     torch.set_num_threads(threads)
     ora = OracleVectorEnv(env.m, env.n, env.k, n)
     ora.boards.copy_(env.boards.cpu())
@@ -130,6 +156,9 @@ def cpu_baseline(env, seconds, threads=0):
         "single_thread_value": steps1 * n / dt1,
         "unit": "env-steps/s",
         "cores": torch.get_num_threads(),
+        "cpu_model": model,
+        "host_logical_cpus": logical,
+        "usable_cpus": usable,
         "kind": "port",
         "sample": f"{steps} plies x {n} envs ({env.m}x{env.n}x{env.k}) from the GPU env's stationary position, "
                   f"{dt:.1f} s; oracle/env_torch.py (torch eager, conv2d win scan) + multinomial RandomPolicy",
@@ -159,6 +188,42 @@ def api_path_rate(env, seed, steps=200):
         ply(1000 + t)
     torch.cuda.synchronize(dev)
     return steps * n / (time.perf_counter() - t0)
+
+
+def api_path_graphed_rate(env, seed, plies_per_graph=64, replays=8):
+    """BASELINE config 2 as the API would be driven in production: the same three launches per ply
+    (mnk_sample_legal -> mnk_step with the legal mask -> mnk_reset_mask), ``plies_per_graph`` plies captured
+    once into a hipGraph (torch.cuda.graph) and replayed -- the Philox step counter advances in device memory
+    (``step_dev``), so every replay plays new plies.  No host launch cost per ply: what is left is the kernels."""
+    n, dev = env.num_envs, env._dev
+    acts = torch.empty(n, dtype=torch.long, device=dev)
+    rew = torch.empty(n, dtype=torch.float32, device=dev)
+    done = torch.empty(n, dtype=torch.bool, device=dev)
+    mask = torch.empty((n, env.max_moves), dtype=torch.bool, device=dev)
+    step_dev = torch.full((1,), 1 << 20, dtype=torch.int64, device=dev)  # away from the eager path's counters
+
+    def body():
+        for t in range(plies_per_graph):
+            env.sample_legal_into(acts, seed=seed, step=t, step_dev=step_dev)
+            env.step_into(acts, rew, done, mask)
+            env.reset_mask_(done)
+        step_dev.add_(plies_per_graph)
+
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        body()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        body()
+    graph.replay()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(replays):
+        graph.replay()
+    torch.cuda.synchronize(dev)
+    return replays * plies_per_graph * n / (time.perf_counter() - t0)
 
 
 def replay_rate(env, roll, chunk, reps=8):
@@ -294,9 +359,35 @@ def selfplay_mode(args):
         "env_steps_per_s": float(state["plies"].item()) / dt,
         "env_side_ms_per_step": env_ms,
         "nn_and_sampling_ms_per_step": dt * 1e3 / steps - env_ms,
-        "roofline": None, "cpu_baseline": None,
+        "roofline": {"note": "not a kernel of this path: 99.7 % of the step is the caller-side network forward "
+                             "(PyTorch-ROCm / MIOpen), which SURVEY.md section 8 puts out of scope; the env-side "
+                             "kernels of this step are timed in profiles/ (api kernels)", "bound": None,
+                     "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None},
+        "cpu_baseline": {"note": "the CPU baseline is reported on the headline workload (default --mode rollout)",
+                         "value": None, "unit": "agent-steps/s", "cores": None, "kind": None, "sample": None},
     }
     print(json.dumps(out), flush=True)
+
+
+def spawn_ranks(n):
+    """``python bench.py --gpus N`` without a launcher: start N fresh rank processes (one per GPU, the env
+    variables torch.distributed.run would set), relay their output -- rank 0 prints the JSON line -- and exit
+    non-zero if any of them does.  Children are new interpreters started BEFORE this process has made any GPU
+    call; nothing is re-exec'ed."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    if any(codes):
+        sys.exit(f"bench.py: rank exit codes {codes}")
 
 
 def main():
@@ -308,11 +399,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+            return spawn_ranks(args.gpus)  # nothing in this process has touched the GPU yet
         args.gpus = world
 
     import mnk_hip
     from env.torch_vector_mnk_env import TorchVectorMnkEnv
+    from selfplay.exchange import RecordExchange
     from selfplay.random_rollout import GatheredLogs, RandomRollout, gather_action_logs
 
     mnk_hip.load()
@@ -336,9 +428,11 @@ def main():
     if mode == "actions":  # a log word holds plies 4q..4q+3: chunks (and so the warm-up) end on multiples of 4
         chunk = args.chunk = max(4, chunk - chunk % 4)
     bufs = [roll.alloc(chunk, log_actions=(mode == "actions")) for _ in range(2)]
-    gathered = side = None
+    gathered = side = exchange = None
     if mode != "none":
         side = torch.cuda.Stream(dev)
+        if args.backend == "nccl":  # the collective goes through the C ABI (mnk_allgather_records), RCCL over xGMI
+            exchange = RecordExchange.from_process_group()
         if mode == "records":
             gathered = [(torch.empty((world,) + tuple(b.planes.shape), dtype=torch.int64, device=dev),
                          torch.empty((world,) + tuple(b.meta.shape), dtype=torch.int32, device=dev)) for b in bufs]
@@ -347,6 +441,7 @@ def main():
     main_stream = torch.cuda.current_stream(dev)
     gather_done = [None, None]
     kernel_events = []  # (start, end) HIP events around every rollout launch of the timed region
+    gather_events = []  # (start, end) HIP events around every all-gather of the timed region, on the side stream
 
     timing = [False]
 
@@ -377,15 +472,24 @@ def main():
                 ready.record(main_stream)
                 with torch.cuda.stream(side):
                     side.wait_event(ready)
+                    if timing[0]:
+                        gs = torch.cuda.Event(enable_timing=True)
+                        gs.record(side)
                     if mode == "actions":
-                        gather_action_logs(out, out=gathered[slot])
+                        gather_action_logs(out, out=gathered[slot], exchange=exchange, stream=side)
                     else:
                         gp, gm = gathered[slot]
-                        dist.all_gather_into_tensor(gp.view(-1), out.planes.view(-1))
-                        dist.all_gather_into_tensor(gm.view(-1), out.meta.view(-1))
-                    ev = torch.cuda.Event()
+                        if exchange is not None:
+                            exchange.all_gather(out.planes.view(-1), gp.view(-1), side)
+                            exchange.all_gather(out.meta.view(-1), gm.view(-1), side)
+                        else:
+                            dist.all_gather_into_tensor(gp.view(-1), out.planes.view(-1))
+                            dist.all_gather_into_tensor(gm.view(-1), out.meta.view(-1))
+                    ev = torch.cuda.Event(enable_timing=timing[0])
                     ev.record(side)
                     gather_done[slot] = ev
+                    if timing[0]:
+                        gather_events.append((gs, ev))
             done += t
             c += 1
         if mode != "none":
@@ -419,6 +523,7 @@ def main():
 
     plies = args.steps * chunk
     value = world * nenv * plies / dt
+    gather_ms = [a.elapsed_time(b) for a, b in gather_events]
     # SURVEY.md section 8d asks for repetitions: four more timed regions of the same K steps (not part of `value`)
     reps = [value]
     timing[0] = False
@@ -498,18 +603,51 @@ def main():
             "achieved_at_survey_B_roll": survey_b_roll * nenv * plies_per_launch / launch_s / 1e9,
         },
     }
+    if mode != "none":
+        if mode == "actions":
+            msg_bytes = bufs[0].msg.numel() * 8
+        else:
+            msg_bytes = bufs[0].planes.numel() * 8 + bufs[0].meta.numel() * 4
+        mean_ms = sum(gather_ms) / max(len(gather_ms), 1)
+        worst = torch.tensor([mean_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        mean_ms = float(worst.item())
+        step_ms = dt * 1e3 / args.steps
+        compute_ms = world * nenv * plies / compute_only * 1e3 / args.steps
+        exposed_ms = max(0.0, step_ms - compute_ms)
+        out["exchange"] = {
+            "what": {"actions": "chunk-start planes | action log (4 plies per word) | chunk-start meta",
+                     "records": "packed records (rows + meta word per ply)"}[mode],
+            "transport": "mnk_allgather_records (C ABI, RCCL)" if exchange is not None
+                         else f"torch.distributed {args.backend}",
+            "bytes_per_rank_per_chunk": msg_bytes,
+            "bytes_per_env_step": msg_bytes / (nenv * chunk),
+            "allgather_ms": mean_ms,                      # slowest rank's mean, HIP events on the side stream
+            "recv_GBps_per_rank": (world - 1) * msg_bytes / (mean_ms * 1e-3) / 1e9 if mean_ms else None,
+            # every peer's message reaches this rank over that peer's own xGMI link (fully connected mesh): the
+            # per-link rate is one message per all-gather time
+            "per_link_GBps": msg_bytes / (mean_ms * 1e-3) / 1e9 if mean_ms else None,
+            "xgmi_link_peak_GBps": 153.0,
+            "compute_ms_per_chunk": compute_ms,
+            "exposed_ms_per_chunk": exposed_ms,           # step time minus the compute-only step time
+            "overlap_fraction": max(0.0, 1.0 - exposed_ms / mean_ms) if mean_ms else None,
+        }
     if rank == 0:
         stats = roll.stats.tolist()
         out["rollout_stats"] = {"episodes": stats[0], "mean_plies": stats[4] / max(stats[0], 1),
                                 "draw_rate": stats[3] / max(stats[0], 1)}
         if world == 1 and not args.no_api_path:
             out["api_path_env_steps_per_s"] = api_path_rate(env, args.seed)
+            out["api_path_graphed_env_steps_per_s"] = api_path_graphed_rate(env, args.seed)
             out["replay_env_steps_per_s"] = replay_rate(env, roll, chunk)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(env, args.cpu_seconds, args.cpu_threads)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+    if exchange is not None:
+        torch.cuda.synchronize(dev)
+        exchange.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

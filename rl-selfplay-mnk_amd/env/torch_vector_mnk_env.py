@@ -324,11 +324,12 @@ class TorchVectorMnkEnv:
                          1 if fix_empty_mask else 0, self._stream())
 
     def sample_legal_into(self, actions, seed: int, step: int, env_id0: int = 0,
-                          stream_id: int = mnk_hip.STREAM_MOVE) -> None:
-        """Uniform legal action per env (the reference's ``RandomPolicy``, policy.py:13-29) from Philox."""
+                          stream_id: int = mnk_hip.STREAM_MOVE, step_dev=None) -> None:
+        """Uniform legal action per env (the reference's ``RandomPolicy``, policy.py:13-29) from Philox.
+        ``step_dev``: optional device int64[1] added to ``step`` (a captured graph's advancing counter)."""
         if self.num_envs:
             mnk_hip.call("mnk_sample_legal", mnk_hip.ptr(self._planes), self.num_envs, self.m, self.n, seed, step,
-                         None, env_id0, stream_id, mnk_hip.ptr(actions), self._stream())
+                         mnk_hip.ptr(step_dev), env_id0, stream_id, mnk_hip.ptr(actions), self._stream())
 
     def reset_mask_(self, mask_u8) -> None:
         """Fixed-shape reset: envs with a non-zero byte in ``mask_u8`` (bool / uint8, (N,)) start over."""

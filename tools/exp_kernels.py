@@ -86,6 +86,9 @@ def main(m=9, n=9, k=5, N=65536):
     lg = torch.randn(N, C, device=DEV)
     sm = RandomPolicy(C)._sampler
     report("sample_logits", timeit(lambda: sm.draw(lg, mask, False)), N * (5 * C + 8), N)
+    lgb = lg.to(torch.bfloat16)
+    report("sample_logits bf16", timeit(lambda: sm.draw(lgb, mask, False)), N * (3 * C + 8), N)
+    report("sample uniform (mask only)", timeit(lambda: sm.draw(None, mask, False)), N * (C + 8), N)
 
 if __name__ == "__main__":
     main()
