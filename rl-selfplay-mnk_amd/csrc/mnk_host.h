@@ -119,3 +119,9 @@ void mnk_launch_rollout_log(const MnkGeom& g, uint64_t* planes, uint32_t* meta, 
 void mnk_launch_rollout_pair(const MnkGeom& g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed,
                              uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
                              void* act_log, int act_bytes, void* stream);
+
+// waves-per-env-group rollout variants (mnk_rollout_ws.hip); ws = 2 or 4
+bool mnk_rollout_ws_supported(const MnkGeom& g, int act_bytes);
+void mnk_launch_rollout_ws(const MnkGeom& g, int ws, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed,
+                           uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
+                           void* act_log, int act_bytes, void* stream);

@@ -57,6 +57,16 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   const bool use_pair = pair_geom &&
                         (pair_override >= 0 ? pair_override != 0 : N <= 32768);
   const bool rec = rec_planes && rec_meta;
+  // MNK_ROLLOUT_FORM=lane|pair|ws2|ws4 forces a kernel form (read per call: A/B timing, parity tests of every form)
+  const char* form = getenv("MNK_ROLLOUT_FORM");
+  int ws = 0;
+  if (form && !strcmp(form, "ws2")) ws = 2;
+  if (form && !strcmp(form, "ws4")) ws = 4;
+  if (ws && mnk_rollout_ws_supported(g, act_bytes)) {
+    mnk_launch_rollout_ws(g, ws, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,
+                          rec ? rec_meta : nullptr, stats, act_log, act_bytes, stream);
+    return mnk_launch_status("rollout_random_ws");
+  }
   if (use_pair) {
     mnk_launch_rollout_pair(g, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,
                             rec ? rec_meta : nullptr, stats, act_log, act_bytes, stream);

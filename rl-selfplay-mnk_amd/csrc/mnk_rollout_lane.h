@@ -20,7 +20,12 @@
 // PAIR: the two-lanes-per-env form for small batches (mnk_rollout_pair.hip): both lanes of a pair carry the env and
 // pick the move redundantly; lane `role` scans two of the four directions (one DPP swap ORs the verdicts), writes
 // half `role` of every record row and stores plane `role` of the final state.
-template <int NW, int CN, int CK, bool RECORD, int ACT = 0, bool PAIR = false>
+// WS > 1: the waves-per-env-group form (mnk_rollout_ws.hip): a workgroup of WS waves carries the SAME 64 envs in
+// every wave; wave `wrole` scans 4 / WS of the four directions with compile-time shifts, the verdicts meet in LDS
+// (one 4-byte write, one s_barrier, one read per ply) and the record rows are split between the waves.  Move
+// selection and the state update are redundant.  Twice / four times the waves of the one-lane form: for batches
+// that leave SIMDs empty or alone with one wave, on boards whose scan dominates the ply (19x19).
+template <int NW, int CN, int CK, bool RECORD, int ACT = 0, bool PAIR = false, int WS = 1>
 struct RolloutLane {
   static constexpr bool EXACT = CN != 0;
   const MnkGeom& g;
@@ -32,6 +37,8 @@ struct RolloutLane {
   int64_t N;
   // this lane's cursors into the record arrays; they advance by one ply's stride after every ply
   uint32_t role = 0;       // PAIR: 0 / 1 within the lane pair
+  uint32_t wrole = 0;      // WS > 1: this wave's index in its workgroup (wave-uniform)
+  uint32_t* vx = nullptr;  // WS > 1: LDS verdicts u32[2][64][WS] (double-buffered by ply parity)
   uint64_t* rp = nullptr;  // rec_planes[t][0][i]
   uint32_t* rp32 = nullptr;  // PAIR: half `role` of rec_planes[t][0][i]
   uint32_t* rm = nullptr;  // rec_meta[t][i]
@@ -42,10 +49,12 @@ struct RolloutLane {
   // to `moves` and a finished game takes its length out, so it is moves(start) + T - moves(end)
   uint32_t acc_done = 0, acc_win = 0, acc_white = 0;
   uint32_t moves_in = 0;
+  uint32_t moves_parity = 0;  // WS > 1: plies played by this launch (selects the verdict buffer)
 
   __device__ __forceinline__ RolloutLane(const MnkGeom& g_, int64_t N_, int64_t i, uint64_t* rec_planes,
-                                         uint32_t* rec_meta, void* act_log, uint32_t role_ = 0)
-      : g(g_), N(N_), role(role_) {
+                                         uint32_t* rec_meta, void* act_log, uint32_t role_ = 0, uint32_t wrole_ = 0,
+                                         uint32_t* vx_ = nullptr)
+      : g(g_), N(N_), role(role_), wrole(wrole_), vx(vx_) {
     if (RECORD) {
       if (PAIR) rp32 = (uint32_t*)(rec_planes + i) + role;
       else rp = rec_planes + i;
@@ -89,6 +98,18 @@ struct RolloutLane {
       rp32 += (int64_t)NW * 2 * N;
       return;
     }
+    if constexpr (WS > 1) {  // wave r writes rows [r*NW/WS, (r+1)*NW/WS): one taken uniform branch per ply
+      static_assert(EXACT, "the waves-per-group form is built for the compile-time boards only");
+#pragma unroll
+      for (int r = 0; r < WS; ++r)
+        if (wrole == (uint32_t)r) {
+#pragma unroll
+          for (int w = r * NW / WS; w < (r + 1) * NW / WS; ++w)
+            __builtin_nontemporal_store((uint64_t)cur[w] | ((uint64_t)oth[w] << 32), rp + (int64_t)w * N);
+        }
+      rp += (int64_t)NW * N;
+      return;
+    }
 #pragma unroll
     for (int w = 0; w < NW; ++w)
       if (EXACT || w < g.NW)
@@ -105,12 +126,14 @@ struct RolloutLane {
     } else {
       store_planes(planes, i);
     }
-    meta[i] = (moves << 1) | side;
+    meta[i] = (moves << 1) | side;  // WS > 1: every wave of the group holds the same state; the kernel lets wave 0 store
   }
 
   __device__ __forceinline__ void log_flush() {
-    if (ACT == 1) *(uint32_t*)ra = (uint32_t)quad;
-    if (ACT == 2) *(uint64_t*)ra = quad;
+    if (WS == 1 || wrole == 0) {
+      if (ACT == 1) *(uint32_t*)ra = (uint32_t)quad;
+      if (ACT == 2) *(uint64_t*)ra = quad;
+    }
     ra += N * 4 * ACT;
     quad = 0;
   }
@@ -175,12 +198,34 @@ struct RolloutLane {
       uint32_t hit = bs_run_bits_pair<NW, CK, CN + 1, CN + 2>(cur, role) | bs_run_bits_pair<NW, CK, 1, CN>(cur, role);
       hit |= pair_swap(hit);  // the partner's two directions
       win = hit ? 1u : 0u;
+    } else if constexpr (WS > 1) {
+      // this wave's share of the four directions (uniform branch, compile-time shifts inside), then the
+      // workgroup's verdicts through LDS: [parity][lane][wave], so the read is one 8 / 16-byte load per lane
+      bool hit = false;
+      if constexpr (WS == 4) {
+        if (wrole == 0) hit = bs_has_run<NW>(cur, 1, CK);
+        else if (wrole == 1) hit = bs_has_run<NW>(cur, CN + 1, CK);
+        else if (wrole == 2) hit = bs_has_run<NW>(cur, CN + 2, CK);
+        else hit = bs_has_run<NW>(cur, CN, CK);
+      } else {
+        if (wrole == 0) hit = bs_has_run<NW>(cur, 1, CK) | bs_has_run<NW>(cur, CN + 1, CK);
+        else hit = bs_has_run<NW>(cur, CN + 2, CK) | bs_has_run<NW>(cur, CN, CK);
+      }
+      uint32_t* slot = vx + ((moves_parity & 1u) * 64u + (threadIdx.x & 63u)) * WS;
+      slot[wrole] = hit ? 1u : 0u;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: the record stores stay in flight
+      uint32_t any = 0;
+#pragma unroll
+      for (int r = 0; r < WS; ++r) any |= slot[r];
+      win = any;
+      ++moves_parity;
     } else {
       win = mnk_plane_wins<NW, CN, CK>(g, cur) ? 1u : 0u;
     }
     const uint32_t done = win | (moves >= (uint32_t)g.C ? 1u : 0u);   // :72-73
     if (RECORD) {
-      __builtin_nontemporal_store((uint32_t)a | (win << MNK_REC_REWARD_SHIFT) | (done << MNK_REC_DONE_BIT) | (side << MNK_REC_SIDE_BIT), rm);
+      if (WS == 1 || wrole == WS - 1)
+        __builtin_nontemporal_store((uint32_t)a | (win << MNK_REC_REWARD_SHIFT) | (done << MNK_REC_DONE_BIT) | (side << MNK_REC_SIDE_BIT), rm);
       rm += N;
     }
     acc_done += done;
