@@ -40,8 +40,10 @@
 #ifndef MNK_HIP_H
 #define MNK_HIP_H
 
+#ifndef __HIPCC_RTC__ /* hiprtc (the run-time specialisation of the rollout kernel) has no libc headers */
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -205,6 +207,15 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
                        uint64_t seed, uint64_t step0, int64_t env_id0,
                        uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
                        void* act_log, int act_bytes, void* stream);
+
+/* Boards other than 3x3x3, 9x9x5, 13x13x5, 15x15x5 and 19x19x5 have no ahead-of-time specialisation of the rollout
+ * kernel; mnk_rollout_random compiles one with hiprtc (about a second, once per board / record / log-width
+ * combination and process) when a launch covers at least 2^20 env-steps -- environment MNK_JIT=1: always, MNK_JIT=0:
+ * never (the kernels with run-time geometry then run, 3-5x slower).  Results are identical either way.
+ * mnk_jit_compile_rollout only compiles (no GPU needed): code object bytes, or a negative status with the
+ * compiler's log in mnk_jit_last_error(). */
+int64_t mnk_jit_compile_rollout(int m, int n, int k, int record, int act_bytes);
+const char* mnk_jit_last_error(void);
 
 /* The multi-GPU exchange format.  A shard's rollout is a pure function of its chunk-start state and
  * its actions, so the action log, optionally written by mnk_rollout_random, is what ranks all-gather

@@ -14,8 +14,23 @@
 // specialised forms turn every shift amount into an immediate and unroll the run
 // doubling; the generic forms keep wave-uniform loops.
 #pragma once
+#ifdef __HIPCC_RTC__
+// compiled at run time by hiprtc (mnk_jit.hip): the HIP device API is built in, libc headers do not exist
+typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
+typedef unsigned int uint32_t;
+typedef unsigned long long uint64_t;
+typedef signed char int8_t;
+typedef int int32_t;
+typedef long long int64_t;
+typedef unsigned long long uintptr_t;
+#include "mnk_hip.h"
+#else
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "../../include/mnk_hip.h"
+#endif
 
 #define MNK_MAX_W 8     // u64 words per plane in memory
 #define MNK_MAX_NW 16   // u32 words per plane in registers

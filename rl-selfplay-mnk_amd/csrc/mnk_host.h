@@ -7,7 +7,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "../../include/mnk_hip.h"
 #include "mnk_device.h"
 #include "mnk_emit.h"
 
@@ -125,3 +124,9 @@ bool mnk_rollout_ws_supported(const MnkGeom& g, int act_bytes);
 void mnk_launch_rollout_ws(const MnkGeom& g, int ws, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed,
                            uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
                            void* act_log, int act_bytes, void* stream);
+
+// run-time specialised rollout kernels (mnk_jit.hip, hiprtc): nullptr when the compile failed
+hipFunction_t mnk_jit_rollout_function(const MnkGeom& g, bool rec, int act);
+int mnk_jit_launch_rollout(hipFunction_t fn, MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed,
+                           uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
+                           void* act_log, void* stream);

@@ -1,0 +1,116 @@
+// mnk_jit.hip -- run-time specialisation of the fused rollout kernel with hiprtc (gfx950 / MI355X only).
+//
+// The rollout kernel is bound by its own instruction count, and a third to a half of those
+// instructions depend on the board: shift amounts of the win scan, word counts, the divisions by n and n+1.  For the
+// boards compiled in ahead of time (3x3x3, 9x9x5, 13x13x5, 15x15x5, 19x19x5) they are immediates; every other (m, n, k)
+// used to run kernels with run-time shift amounts and wave-uniform loops at a third to a fifth of that rate.
+// Here the first large launch on such a board compiles `mnk_rollout_lane.h` -- the very text hipcc compiles for the
+// built-in boards, embedded in this library at build time -- with the board's NW / n / k as template arguments, and
+// every later launch runs that code object.  One compile per (board, record?, log width) and process, a few seconds.
+// The reference (env/torch_vector_mnk_env.py:7-32) takes any m, n, k; this keeps every board on the fast path.
+#include <hip/hiprtc.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "mnk_host.h"
+#include "_obj/mnk_jit_sources.inc"  // MNK_JIT_HEADER_COUNT, mnk_jit_header_names[], mnk_jit_header_texts[]
+
+namespace {
+
+struct Compiled {
+  hipModule_t module = nullptr;
+  hipFunction_t fn = nullptr;
+  size_t code_bytes = 0;
+  bool failed = false;
+};
+
+std::mutex g_mu;
+std::map<std::tuple<int, int, int, int, int>, Compiled> g_cache;
+thread_local char g_jit_err[2048] = "";
+
+// compiles the rollout kernel for this geometry; code object bytes in `code` (no GPU needed for this part)
+bool compile(const MnkGeom& g, bool rec, int act, std::vector<char>& code) {
+  static const char* program =
+      "#include \"mnk_rollout_lane.h\"\n";
+  hiprtcProgram prog = nullptr;
+  if (hiprtcCreateProgram(&prog, program, "mnk_jit_rollout.hip", MNK_JIT_HEADER_COUNT, mnk_jit_header_texts,
+                          mnk_jit_header_names) != HIPRTC_SUCCESS) {
+    snprintf(g_jit_err, sizeof(g_jit_err), "hiprtcCreateProgram failed");
+    return false;
+  }
+  const std::string d_nw = "-DMNK_JIT_NW=" + std::to_string(g.NW), d_cn = "-DMNK_JIT_CN=" + std::to_string(g.n),
+                    d_ck = "-DMNK_JIT_CK=" + std::to_string(g.k), d_rec = "-DMNK_JIT_REC=" + std::to_string(rec ? 1 : 0),
+                    d_act = "-DMNK_JIT_ACT=" + std::to_string(act);
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", d_nw.c_str(), d_cn.c_str(),
+                        d_ck.c_str(), d_rec.c_str(), d_act.c_str()};
+  const hiprtcResult rc = hiprtcCompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+  if (rc != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n, '\0');
+    if (n) hiprtcGetProgramLog(prog, &log[0]);
+    snprintf(g_jit_err, sizeof(g_jit_err), "hiprtc: %s\n%.1800s", hiprtcGetErrorString(rc), log.c_str());
+    hiprtcDestroyProgram(&prog);
+    return false;
+  }
+  size_t n = 0;
+  hiprtcGetCodeSize(prog, &n);
+  code.resize(n);
+  hiprtcGetCode(prog, code.data());
+  hiprtcDestroyProgram(&prog);
+  return n > 0;
+}
+
+}  // namespace
+
+// kernel of this geometry, compiled on first use; nullptr (and mnk_jit_last_error) when that failed -- the caller
+// then stays on the ahead-of-time generic kernel
+hipFunction_t mnk_jit_rollout_function(const MnkGeom& g, bool rec, int act) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  Compiled& c = g_cache[std::make_tuple(g.m, g.n, g.k, rec ? 1 : 0, act)];
+  if (c.fn || c.failed) return c.fn;
+  std::vector<char> code;
+  if (!compile(g, rec, act, code)) { c.failed = true; return nullptr; }
+  if (hipModuleLoadData(&c.module, code.data()) != hipSuccess ||
+      hipModuleGetFunction(&c.fn, c.module, "mnk_jit_rollout") != hipSuccess) {
+    snprintf(g_jit_err, sizeof(g_jit_err), "hipModuleLoadData / hipModuleGetFunction failed: %s",
+             hipGetErrorString(hipGetLastError()));
+    c.failed = true;
+    c.fn = nullptr;
+    return nullptr;
+  }
+  c.code_bytes = code.size();
+  return c.fn;
+}
+
+int mnk_jit_launch_rollout(hipFunction_t fn, MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed,
+                           uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
+                           void* act_log, void* stream) {
+  void* args[] = {&g, &planes, &meta, &N, &T, &seed, &step0, &env_id0, &rec_planes, &rec_meta, &stats, &act_log};
+  const unsigned grid = (unsigned)((N + 63) / 64);
+  if (hipModuleLaunchKernel(fn, grid, 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args, nullptr) != hipSuccess)
+    return mnk_launch_status("rollout_random (run-time specialised)");
+  return MNK_OK;
+}
+
+extern "C" {
+
+const char* mnk_jit_last_error(void) { return g_jit_err; }
+
+// Compiles (does not load) the rollout kernel of a geometry: code object size in bytes, or a negative MNK_E* code.
+// Needs no GPU -- the build check and the CPU test suite use it.
+int64_t mnk_jit_compile_rollout(int m, int n, int k, int record, int act_bytes) {
+  MnkGeom g;
+  const int rc = mnk_check_geom(m, n, k, &g);
+  if (rc != MNK_OK) return rc;
+  if (act_bytes < 0 || act_bytes > 2) return MNK_EINVAL;
+  std::vector<char> code;
+  if (!compile(g, record != 0, act_bytes, code)) return MNK_ELAUNCH;
+  return (int64_t)code.size();
+}
+
+}  // extern "C"

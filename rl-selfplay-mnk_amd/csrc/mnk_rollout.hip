@@ -1,6 +1,7 @@
 // mnk_rollout.hip -- the fused random-policy rollout and the replay of its action log
 // (gfx950 / MI355X only).  Separate translation unit: these kernels come in many variants
 // (board specialisation x record / action-log forms) and compile in parallel with the rest.
+#include "mnk_host.h"
 #include "mnk_rollout_lane.h"
 
 // ------------------------------------------------------------------ replay of an action log
@@ -66,6 +67,18 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
     mnk_launch_rollout_ws(g, ws, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,
                           rec ? rec_meta : nullptr, stats, act_log, act_bytes, stream);
     return mnk_launch_status("rollout_random_ws");
+  }
+  // A board without an ahead-of-time specialisation gets one at run time (mnk_jit.hip) once a launch is large
+  // enough to pay for the ~1 s of compilation: MNK_JIT=1 always, MNK_JIT=0 never, unset = from 2^20 env-steps per
+  // launch (4 096 envs x 256 plies).  If the compile fails the generic kernel below still runs.
+  if (!pair_geom) {
+    const char* jit_env = getenv("MNK_JIT");
+    const bool want = jit_env ? atoi(jit_env) != 0 : (N * (int64_t)T >= (1ll << 20));
+    if (want) {
+      if (hipFunction_t fn = mnk_jit_rollout_function(g, rec, act_bytes))
+        return mnk_jit_launch_rollout(fn, g, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,
+                                      rec ? rec_meta : nullptr, stats, act_log, stream);
+    }
   }
   if (use_pair) {
     mnk_launch_rollout_pair(g, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,

@@ -2,8 +2,10 @@
 // translation units that instantiate it: mnk_rollout.hip (no action log; also the replay kernel),
 // mnk_rollout_log.hip (the action-log variants) and mnk_rollout_pair.hip (two lanes per env).  Split so that
 // the many instantiations compile in parallel.
+// Device code only (no host headers): the same text is compiled ahead of time by hipcc for the built-in boards
+// and at run time by hiprtc, with the board's geometry as template arguments, for every other board (mnk_jit.hip).
 #pragma once
-#include "mnk_host.h"
+#include "mnk_device.h"
 #include "mnk_pair_scan.h"
 
 // ------------------------------------------------------------------ fused random rollout
@@ -243,11 +245,12 @@ struct RolloutLane {
   }
 };
 
+// the one-lane kernel's body: one wave of 64 envs per workgroup of 64 threads
 template <int NW, int CN, int CK, bool RECORD, int ACT>
-__global__ void __launch_bounds__(64)
-k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed, uint64_t step0,
-                 int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, unsigned long long* stats,
-                 void* act_log) {
+__device__ __forceinline__ void rollout_random_body(const MnkGeom& g, uint64_t* planes, uint32_t* meta, int64_t N, int T,
+                                                    uint64_t seed, uint64_t step0, int64_t env_id0,
+                                                    uint64_t* rec_planes, uint32_t* rec_meta, unsigned long long* stats,
+                                                    void* act_log) {
   // one full wave of 64 envs per workgroup: half-filled waves were measured and are slower
   // (gfx950 does not skip the idle half of a wave64), see DESIGN.md
   __shared__ unsigned int lds_stats[MNK_STATS_COUNTERS];
@@ -294,3 +297,21 @@ k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, 
               (unsigned long long)lds_stats[threadIdx.x]);
 }
 
+#ifdef MNK_JIT_NW
+// run-time specialisation (mnk_jit.hip): this board's geometry arrives as macros on the hiprtc command line
+extern "C" __global__ void __launch_bounds__(64)
+mnk_jit_rollout(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed, uint64_t step0,
+                int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, unsigned long long* stats, void* act_log) {
+  rollout_random_body<MNK_JIT_NW, MNK_JIT_CN, MNK_JIT_CK, MNK_JIT_REC != 0, MNK_JIT_ACT>(
+      g, planes, meta, N, T, seed, step0, env_id0, rec_planes, rec_meta, stats, act_log);
+}
+#else
+template <int NW, int CN, int CK, bool RECORD, int ACT>
+__global__ void __launch_bounds__(64)
+k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed, uint64_t step0,
+                 int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, unsigned long long* stats,
+                 void* act_log) {
+  rollout_random_body<NW, CN, CK, RECORD, ACT>(g, planes, meta, N, T, seed, step0, env_id0, rec_planes, rec_meta, stats,
+                                               act_log);
+}
+#endif

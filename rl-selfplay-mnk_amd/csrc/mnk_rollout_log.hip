@@ -1,5 +1,6 @@
 // mnk_rollout_log.hip -- the fused random rollout with the action log switched on (gfx950 / MI355X only):
 // the variants the multi-GPU exchange uses.  Its own translation unit so it compiles beside mnk_rollout.hip.
+#include "mnk_host.h"
 #include "mnk_rollout_lane.h"
 
 void mnk_launch_rollout_log(const MnkGeom& g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed,

@@ -1,5 +1,6 @@
 // mnk_rollout_pair.hip -- the two-lanes-per-env form of the fused random rollout (gfx950 / MI355X only).
 // Its own translation unit so the many variants compile in parallel with the one-lane kernels.
+#include "mnk_host.h"
 #include "mnk_rollout_lane.h"
 
 // ------------------------------------------------------------------ two lanes per env

@@ -1,5 +1,6 @@
 // mnk_rollout_ws.hip -- the waves-per-env-group form of the fused random rollout (gfx950 / MI355X only).
 // Its own translation unit so its variants compile in parallel with the other rollout kernels.
+#include "mnk_host.h"
 #include "mnk_rollout_lane.h"
 
 // ------------------------------------------------------------------ WS waves per group of 64 envs

@@ -54,6 +54,8 @@ SIGNATURES = {
     "mnk_unpack_records": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "mnk_gather_obs": [_vp, _i64, _i64, _i, _i, _vp, _i64, _vp, _vp, _i, _vp, _vp],
     "mnk_gae": [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp],
+    "mnk_jit_compile_rollout": [_i, _i, _i, _i, _i],
+    "mnk_jit_last_error": [],
     "mnk_comm_unique_id": [_vp],
     "mnk_comm_init": [_vp, _vp, _i, _i],
     "mnk_comm_destroy": [_vp],
@@ -87,7 +89,12 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header / library mismatch
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_char_p if name in ("mnk_last_launch_error", "mnk_comm_last_error") else ctypes.c_int
+        if name in ("mnk_last_launch_error", "mnk_comm_last_error", "mnk_jit_last_error"):
+            fn.restype = ctypes.c_char_p
+        elif name == "mnk_jit_compile_rollout":
+            fn.restype = ctypes.c_int64
+        else:
+            fn.restype = ctypes.c_int
     if lib.mnk_abi_version() != ABI_VERSION:
         raise MnkHipError(f"libmnk_hip.so ABI {lib.mnk_abi_version()} != binding ABI {ABI_VERSION}")
     _lib = lib

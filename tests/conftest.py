@@ -11,6 +11,14 @@ for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# the oracle is torch-eager on small batches: a GPU box's 256 logical CPUs make every tiny op slower, not faster
+try:
+    import torch
+
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+except ImportError:  # pragma: no cover
+    pass
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -23,7 +23,7 @@ def lib():
 def declared_functions():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    decls = re.findall(r"\b(?:int|const char\*)\s+(mnk_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S)
+    decls = re.findall(r"\b(?:int|int64_t|const char\*)\s+(mnk_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S)
     out = {}
     for name, args in decls:
         args = args.strip()
@@ -74,3 +74,14 @@ def test_product_path_has_no_cpu_mode(lib):
         TorchVectorMnkEnv(3, 3, 3, 4, device="cpu")
     with pytest.raises(AssertionError):
         TorchVectorMnkEnv(3, 3, 4, 4, device="cpu")  # reference env:9
+
+
+def test_rollout_kernel_specialises_at_run_time_without_a_gpu(lib):
+    """hiprtc compiles the rollout kernel for boards that have no ahead-of-time specialisation (csrc/mnk_jit.hip);
+    compiling needs no GPU, so the build container checks that the embedded headers still compile for gfx950."""
+    handle = lib.load()
+    for (m, n, k, rec, act) in [(12, 12, 5, 1, 0), (7, 9, 7, 0, 1), (22, 22, 10, 1, 2)]:
+        size = handle.mnk_jit_compile_rollout(m, n, k, rec, act)
+        assert size > 4096, (handle.mnk_jit_last_error() or b"").decode()
+    assert handle.mnk_jit_compile_rollout(30, 30, 5, 1, 0) == -2   # MNK_EGEOM: beyond the packed layout
+    assert handle.mnk_jit_compile_rollout(9, 9, 5, 1, 3) == -1     # MNK_EINVAL: log width

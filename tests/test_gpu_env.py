@@ -26,6 +26,7 @@ def hip():
     entry._ensure_path()
     import mnk_hip
     from env.torch_vector_mnk_env import TorchVectorMnkEnv
+    from selfplay import random_rollout
     from selfplay.random_rollout import RandomRollout
 
     mnk_hip.load()
@@ -35,7 +36,7 @@ def hip():
         pass
 
     ns = NS()
-    ns.lib, ns.Env, ns.Rollout = mnk_hip, TorchVectorMnkEnv, RandomRollout
+    ns.lib, ns.Env, ns.Rollout, ns.rollout = mnk_hip, TorchVectorMnkEnv, RandomRollout, random_rollout
     return ns
 
 
@@ -159,23 +160,40 @@ def test_sample_legal_matches_oracle(hip, m, n, k, nenv):
         assert np.array_equal(acts.cpu().numpy(), philox.pick_legal(legal, x))
 
 
+def _force_form(param):
+    saved = {key: os.environ.get(key) for key in ("MNK_ROLLOUT_PAIR", "MNK_ROLLOUT_FORM")}
+    os.environ.pop("MNK_ROLLOUT_FORM", None)
+    os.environ["MNK_ROLLOUT_PAIR"] = "1" if param.startswith("two lanes") else "0"
+    if "waves" in param:
+        os.environ["MNK_ROLLOUT_FORM"] = "ws2" if param.startswith("two") else "ws4"
+    return saved
+
+
+def _restore_form(saved):
+    for key, val in saved.items():
+        if val is None:
+            os.environ.pop(key, None)
+        else:
+            os.environ[key] = val
+
+
+@pytest.fixture(params=["one lane per env", "two lanes per env"])
+def lane_or_pair(request):
+    """the two forms that can write the action log"""
+    saved = _force_form(request.param)
+    yield request.param
+    _restore_form(saved)
+
+
 @pytest.fixture(params=["one lane per env", "two lanes per env", "two waves per env group", "four waves per env group"])
 def lanes_per_env(request):
     """The launcher picks the rollout kernel form by board and batch size; MNK_ROLLOUT_PAIR / MNK_ROLLOUT_FORM (read
     on every call) force one, so small test batches reach every form.  Boards without a compile-time specialisation
     have the one-lane form only; the waves-per-group forms exist for 9x9x5 and 19x19x5 (others fall through to the
     launcher's own choice)."""
-    saved = {key: os.environ.get(key) for key in ("MNK_ROLLOUT_PAIR", "MNK_ROLLOUT_FORM")}
-    os.environ.pop("MNK_ROLLOUT_FORM", None)
-    os.environ["MNK_ROLLOUT_PAIR"] = "1" if request.param.startswith("two lanes") else "0"
-    if "waves" in request.param:
-        os.environ["MNK_ROLLOUT_FORM"] = "ws2" if request.param.startswith("two") else "ws4"
+    saved = _force_form(request.param)
     yield request.param
-    for key, val in saved.items():
-        if val is None:
-            os.environ.pop(key, None)
-        else:
-            os.environ[key] = val
+    _restore_form(saved)
 
 
 @pytest.mark.parametrize("m,n,k", [(3, 3, 3), (9, 9, 5), (19, 19, 5), (7, 9, 7), (22, 22, 5)])
@@ -294,7 +312,7 @@ def test_full_size_rollout_properties(hip, m, n, k, nenv, steps, tail, mean_lo, 
 
 @pytest.mark.parametrize("m,n,k,nenv,steps", [(3, 3, 3, 70, 40), (9, 9, 5, 200, 130), (19, 19, 5, 65, 90),
                                               (13, 13, 5, 5, 150), (7, 9, 7, 64, 81), (9, 9, 5, 64, 6)])
-def test_action_log_replay_rebuilds_the_records(hip, m, n, k, nenv, steps, lanes_per_env):
+def test_action_log_replay_rebuilds_the_records(hip, m, n, k, nenv, steps, lane_or_pair):
     """The multi-GPU exchange format: chunk-start state + action log (1-2 B per ply).
     mnk_replay_actions on the log == the records the rollout wrote (bit for bit) == the oracle's
     replay of the same log; a second chunk checks that the state carried over."""
@@ -358,18 +376,38 @@ def _fuzz_geometries(count, seed):
 @pytest.mark.parametrize("m,n,k", _fuzz_geometries(24, seed=2026) + [(22, 22, 10), (9, 9, 4), (9, 9, 9), (2, 22, 2),
                                                                       (22, 2, 2), (15, 15, 5), (12, 9, 5)])
 def test_generic_geometries_match_oracle(hip, m, n, k):
-    """Boards outside the compile-time specialisations (and odd ones inside them): the generic kernels with
-    run-time shifts -- including shift amounts >= 32 and k up to 10 -- against the oracle: a fused rollout
-    (records, statistics, final state) and an API-level step with observation and mask, bit for bit."""
+    """Boards outside the ahead-of-time specialisations (and odd ones inside them), both ways they can run: the
+    generic kernels with run-time shifts (MNK_JIT=0) -- including shift amounts >= 32 and k up to 10 -- and the
+    kernel hiprtc compiles for exactly this board (MNK_JIT=1), against the oracle: a fused rollout (records,
+    statistics, final state) and an API-level step with observation and mask, bit for bit."""
     nenv, steps = 67, 3 * max(m, n)
-    env = hip.Env(m, n, k, nenv, device=DEV)
-    roll = hip.Rollout(env, seed=m * 1000 + n * 10 + k)
     ora = OracleVectorEnv(m, n, k, nenv)
-    rec = roll.run(steps)
     planes, meta, stats = random_rollout(ora, seed=m * 1000 + n * 10 + k, step0=0, steps=steps)
-    assert np.array_equal(rec.planes.cpu().numpy().view(np.uint64), planes)
-    assert np.array_equal(rec.meta.cpu().numpy().view(np.uint32), meta)
-    assert np.array_equal(roll.stats.cpu().numpy(), stats)
+    saved = os.environ.get("MNK_JIT")
+    try:
+        for jit in ("0", "1"):
+            os.environ["MNK_JIT"] = jit
+            env = hip.Env(m, n, k, nenv, device=DEV)
+            roll = hip.Rollout(env, seed=m * 1000 + n * 10 + k)
+            rec = roll.run(steps)
+            assert np.array_equal(rec.planes.cpu().numpy().view(np.uint64), planes), f"MNK_JIT={jit}"
+            assert np.array_equal(rec.meta.cpu().numpy().view(np.uint32), meta), f"MNK_JIT={jit}"
+            assert np.array_equal(roll.stats.cpu().numpy(), stats), f"MNK_JIT={jit}"
+            assert torch.equal(env.move_counts.cpu(), ora.move_counts), f"MNK_JIT={jit}"
+            # split launches, action log on: the head / tail paths of the specialised kernel
+            env2 = hip.Env(m, n, k, nenv, device=DEV)
+            roll2 = hip.Rollout(env2, seed=m * 1000 + n * 10 + k)
+            first = max(4, (steps // 8) * 4)
+            a = roll2.alloc(first, log_actions=True)
+            roll2.run(first, out=a)
+            b = roll2.run(steps - first)
+            assert torch.equal(torch.cat([a.planes, b.planes]), rec.planes) and torch.equal(torch.cat([a.meta, b.meta]), rec.meta)
+            assert torch.equal(hip.rollout.unpack_action_log(a.act, first), rec.actions()[:first])
+    finally:
+        if saved is None:
+            os.environ.pop("MNK_JIT", None)
+        else:
+            os.environ["MNK_JIT"] = saved
     acts = torch.from_numpy(np.random.default_rng(k).integers(-m * n, m * n, nenv))
     o1, r1, d1 = env.step(acts.to(DEV))
     o2, r2, d2 = ora.step(acts)
