@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 # (FETCH_SIZE x 1024 x 2 [gfx950 correction] + WRITE_SIZE x 1024), keyed by (board, envs/GPU, chunk).
 # bench.py cannot run rocprofv3 on itself; configurations without a committed profile report null.
 PMC_TRAFFIC = {
-    ("9x9x5", 65536, 256): (474.67e6, "profiles/r01_rollout_9x9x5.md"),
+    ("9x9x5", 65536, 256): (474.67e6, "profiles/r02_rollout_9x9x5.md"),
 }
 
 

@@ -91,5 +91,9 @@ def main(m=9, n=9, k=5, N=65536):
     report("sample uniform (mask only)", timeit(lambda: sm.draw(None, mask, False)), N * (C + 8), N)
 
 if __name__ == "__main__":
-    main()
-    main(19, 19, 5, 32768)
+    if len(sys.argv) > 1:  # exp_kernels.py 9x9x5 262144 ...
+        for board, nenv in zip(sys.argv[1::2], sys.argv[2::2]):
+            main(*(int(v) for v in board.split("x")), int(nenv))
+    else:
+        main()
+        main(19, 19, 5, 32768)

@@ -37,10 +37,12 @@ BYTES = {
     "k_selfplay_pre<12, 19, 5>": (N19 * (S19 + 8 * W19 + 4 + 9 * C19 + 8 + 1 + 8 + 4 + 1 + 1), "agent ply + opponent's obs + mask"),
     "k_selfplay_post<3, 9, 5>": (N9 * (S9 + 8 * W9 + 4 + 9 * C9 + 8 + 1 + 8 + 8 + 2 + 1), "opponent ply + agent's obs + mask"),
     "k_selfplay_post<12, 19, 5>": (N19 * (S19 + 8 * W19 + 4 + 9 * C19 + 8 + 1 + 8 + 8 + 2 + 1), "opponent ply + agent's obs + mask"),
-    "k_sample_logits<8, 11, float>": (N9 * (5 * C9 + 8), "65 536 rows x 81 f32 logits + mask in, action out"),
-    "k_sample_logits<32, 12, float>": (N19 * (5 * C19 + 8), "32 768 rows x 361 f32 logits + mask in, action out"),
-    "k_sample_logits<8, 11, unsigned short>": (N9 * (3 * C9 + 8), "65 536 rows x 81 bf16 logits + mask in, action out"),
-    "k_sample_logits<32, 12, unsigned short>": (N19 * (3 * C19 + 8), "32 768 rows x 361 bf16 logits + mask in, action out"),
+    "k_sample_logits<4, 21, true, float>": (N9 * (5 * C9 + 12), "65 536 rows x 81 f32 logits + mask in, action + log-prob out"),
+    "k_sample_logits<4, 21, true, unsigned short>": (N9 * (3 * C9 + 12), "65 536 rows x 81 bf16 logits + mask in"),
+    "k_sample_logits<4, 21, true, void>": (N9 * (C9 + 12), "65 536 rows x 81 mask bytes in (uniform draw, RandomPolicy)"),
+    "k_sample_logits<16, 23, true, float>": (N19 * (5 * C19 + 12), "32 768 rows x 361 f32 logits + mask in, action + log-prob out"),
+    "k_sample_logits<16, 23, true, unsigned short>": (N19 * (3 * C19 + 12), "32 768 rows x 361 bf16 logits + mask in"),
+    "k_sample_logits<16, 23, true, void>": (N19 * (C19 + 12), "32 768 rows x 361 mask bytes in (uniform draw)"),
     "k_sample_legal<3, 9, 5>": (N9 * (S9 - 4 + 8), "planes in, action i64 out"),
     "k_sample_legal<12, 19, 5>": (N19 * (S19 - 4 + 8), "planes in, action i64 out"),
     "k_gae": (None, "rewards, values, dones in; advantages, returns out (17 B per step and env; two shapes mixed)"),
