@@ -13,12 +13,16 @@ The reference tree never travels to the GPU box, so nothing here is imported by
 the GPU tests; ``tests/test_oracle_golden.py`` runs it (fixed cases + a hypothesis property test) when the tree is present and
 the golden fixtures cover the rest.
 
-Usage:  python -m oracle.pin_against_reference
+Usage:  python -m oracle.pin_against_reference     (or: python oracle/pin_against_reference.py)
 """
 import os
 import sys
 
 import torch
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _ROOT not in sys.path:  # run as a script: make `oracle` importable as a package
+    sys.path.insert(0, _ROOT)
 
 REFERENCE_SRC = "/root/reference/src"
 
@@ -70,7 +74,7 @@ def _same_obs(a, b, what: str):
 
 def check_env(m, n, k, nenv, steps, seed, illegal_rate=0.15, subset_rate=0.5):
     RefEnv, _, _ = import_reference()
-    from .env_torch import OracleVectorEnv
+    from oracle.env_torch import OracleVectorEnv
 
     g = torch.Generator().manual_seed(seed)
     ref, ora = RefEnv(m, n, k, nenv, device="cpu"), OracleVectorEnv(m, n, k, nenv)
@@ -108,9 +112,9 @@ def check_env(m, n, k, nenv, steps, seed, illegal_rate=0.15, subset_rate=0.5):
 
 def check_selfplay(m, n, k, nenv, steps, seed, opponent="random", fixed_sides=None):
     RefEnv, RefWrap, RefRandom = import_reference()
-    from .env_torch import OracleVectorEnv
-    from .policies import HighestLegalPolicy, LowestLegalPolicy, MaskHashPolicy, OracleRandomPolicy
-    from .selfplay_torch import OracleSelfPlay
+    from oracle.env_torch import OracleVectorEnv
+    from oracle.policies import HighestLegalPolicy, LowestLegalPolicy, MaskHashPolicy, OracleRandomPolicy
+    from oracle.selfplay_torch import OracleSelfPlay
 
     def make_opp(is_ref):
         if opponent == "random":
