@@ -432,7 +432,17 @@ def main():
     if mode != "none":
         side = torch.cuda.Stream(dev)
         if args.backend == "nccl":  # the collective goes through the C ABI (mnk_allgather_records), RCCL over xGMI
-            exchange = RecordExchange.from_process_group()
+            try:
+                exchange = RecordExchange.from_process_group()
+            except Exception as e:  # noqa: BLE001 -- the same all-gather through torch.distributed's RCCL instead
+                print(f"[bench rank {rank}] C-ABI communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+                exchange = None
+            # every rank must take the same path
+            ok = torch.tensor([1 if exchange is not None else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and exchange is not None:
+                exchange.close()
+                exchange = None
         if mode == "records":
             gathered = [(torch.empty((world,) + tuple(b.planes.shape), dtype=torch.int64, device=dev),
                          torch.empty((world,) + tuple(b.meta.shape), dtype=torch.int32, device=dev)) for b in bufs]
