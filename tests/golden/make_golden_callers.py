@@ -224,6 +224,10 @@ def make_ppo_learn_with_last_values(*case):
 
 
 def main():
+    # one intra-op thread: the PPO update between the two learn() calls reduces gradients over the batch, and the
+    # sampled actions of the second call depend on the last bits of those sums -- with one thread the fixture
+    # regenerates byte for byte on any machine
+    torch.set_num_threads(1)
     for name, maker in (("gae", make_gae), ("validate", make_validate), ("tournament", make_tournament)):
         path = os.path.join(OUT, name + ".npz")
         np.savez_compressed(path, **maker())
