@@ -269,6 +269,8 @@ def test_rollout_is_independent_of_sharding(hip):
 @pytest.mark.parametrize("m,n,k,nenv,steps,tail,mean_lo,mean_hi,draw_lo,draw_hi", [
     (9, 9, 5, 65536, 160, 640, 53.2, 53.7, 0.0020, 0.0034),       # BASELINE configs 2 / 4: one lane per env
     (19, 19, 5, 32768, 120, 2400, 152.5, 154.5, 0.0, 1e-4),       # BASELINE config 5's per-GPU batch: two lanes per env
+    (9, 9, 5, 1 << 20, 24, 776, 53.2, 53.7, 0.0020, 0.0034),      # 16 x the headline batch: 64-bit indexing, 16 waves per SIMD
+    (12, 12, 5, 65536, 64, 1216, 78.8, 79.8, 0.0, 1e-4),          # no built-in variant: the run-time specialised kernel
 ])
 def test_full_size_rollout_properties(hip, m, n, k, nenv, steps, tail, mean_lo, mean_hi, draw_lo, draw_hi):
     """BASELINE.json sizes: properties that need no oracle run -- every recorded action was legal on the recorded
