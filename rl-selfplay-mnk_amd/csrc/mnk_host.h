@@ -130,3 +130,9 @@ hipFunction_t mnk_jit_rollout_function(const MnkGeom& g, bool rec, int act);
 int mnk_jit_launch_rollout(hipFunction_t fn, MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed,
                            uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
                            void* act_log, void* stream);
+
+// two lanes per env with the board split by words (mnk_rollout_pairw.hip): 19x19x5 and 15x15x5
+bool mnk_rollout_pairw_supported(const MnkGeom& g);
+void mnk_launch_rollout_pairw(const MnkGeom& g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed,
+                              uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
+                              void* act_log, int act_bytes, void* stream);

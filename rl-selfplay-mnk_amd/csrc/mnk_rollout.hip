@@ -80,6 +80,16 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
                                       rec ? rec_meta : nullptr, stats, act_log, stream);
     }
   }
+  // two lanes per env: split by WORDS on the boards where that measured faster (us per 256 plies at 32 768 envs,
+  // by directions / by words: 19x19 216 / 164, 15x15 155 / 135, 13x13 127 / 117; 9x9 86 / 98 stays split by
+  // directions); MNK_ROLLOUT_FORM=pair|pairw forces one (pairw at any batch size)
+  const bool force_w = form && !strcmp(form, "pairw");
+  const bool force_d = form && !strcmp(form, "pair");
+  if (mnk_rollout_pairw_supported(g) && (force_w || (use_pair && !force_d && g.n >= 13))) {
+    mnk_launch_rollout_pairw(g, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,
+                             rec ? rec_meta : nullptr, stats, act_log, act_bytes, stream);
+    return mnk_launch_status("rollout_random_pairw");
+  }
   if (use_pair) {
     mnk_launch_rollout_pair(g, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,
                             rec ? rec_meta : nullptr, stats, act_log, act_bytes, stream);

@@ -166,6 +166,8 @@ def _force_form(param):
     os.environ["MNK_ROLLOUT_PAIR"] = "1" if param.startswith("two lanes") else "0"
     if "waves" in param:
         os.environ["MNK_ROLLOUT_FORM"] = "ws2" if param.startswith("two") else "ws4"
+    elif param.startswith("two lanes"):  # split by scan directions, or by board words (19x19 / 15x15 only)
+        os.environ["MNK_ROLLOUT_FORM"] = "pairw" if "words" in param else "pair"
     return saved
 
 
@@ -177,7 +179,7 @@ def _restore_form(saved):
             os.environ[key] = val
 
 
-@pytest.fixture(params=["one lane per env", "two lanes per env"])
+@pytest.fixture(params=["one lane per env", "two lanes per env", "two lanes per env, words split"])
 def lane_or_pair(request):
     """the two forms that can write the action log"""
     saved = _force_form(request.param)
@@ -185,7 +187,8 @@ def lane_or_pair(request):
     _restore_form(saved)
 
 
-@pytest.fixture(params=["one lane per env", "two lanes per env", "two waves per env group", "four waves per env group"])
+@pytest.fixture(params=["one lane per env", "two lanes per env", "two lanes per env, words split",
+                        "two waves per env group", "four waves per env group"])
 def lanes_per_env(request):
     """The launcher picks the rollout kernel form by board and batch size; MNK_ROLLOUT_PAIR / MNK_ROLLOUT_FORM (read
     on every call) force one, so small test batches reach every form.  Boards without a compile-time specialisation
@@ -234,7 +237,8 @@ def test_sample_legal_reaches_every_cell_and_every_rank(hip, m, n, k):
 @pytest.mark.parametrize("m,n,k,nenv,chunks", [(3, 3, 3, 64, (7, 9, 16)), (9, 9, 5, 333, (64, 31)),
                                                (3, 3, 3, 3, (30,)), (9, 9, 5, 1, (5, 6, 200)), (5, 6, 4, 129, (61,)),
                                                (4, 6, 3, 100, (40,)), (13, 13, 5, 65, (120,)),
-                                               (19, 19, 5, 64, (200,)), (7, 9, 7, 70, (90,))])
+                                               (19, 19, 5, 64, (200,)), (7, 9, 7, 70, (90,)),
+                                               (15, 15, 5, 33, (37, 130)), (19, 19, 5, 31, (3, 9, 190))])
 def test_rollout_matches_oracle(hip, m, n, k, nenv, chunks, lanes_per_env):
     """mnk_rollout_random == oracle loop (sample -> step -> reset done), records, stats and final
     state bit for bit; several launches continue the same Philox step counter.  Both kernel forms: one lane per
@@ -313,7 +317,8 @@ def test_full_size_rollout_properties(hip, m, n, k, nenv, steps, tail, mean_lo, 
 
 
 @pytest.mark.parametrize("m,n,k,nenv,steps", [(3, 3, 3, 70, 40), (9, 9, 5, 200, 130), (19, 19, 5, 65, 90),
-                                              (13, 13, 5, 5, 150), (7, 9, 7, 64, 81), (9, 9, 5, 64, 6)])
+                                              (13, 13, 5, 5, 150), (7, 9, 7, 64, 81), (9, 9, 5, 64, 6),
+                                              (15, 15, 5, 40, 120)])
 def test_action_log_replay_rebuilds_the_records(hip, m, n, k, nenv, steps, lane_or_pair):
     """The multi-GPU exchange format: chunk-start state + action log (1-2 B per ply).
     mnk_replay_actions on the log == the records the rollout wrote (bit for bit) == the oracle's

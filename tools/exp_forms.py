@@ -11,7 +11,7 @@ from env.torch_vector_mnk_env import TorchVectorMnkEnv
 from selfplay.random_rollout import RandomRollout
 
 DEV = "cuda:0"
-FORMS = {"lane": ("0", None), "pair": ("1", None), "ws2": ("0", "ws2"), "ws4": ("0", "ws4")}
+FORMS = {"lane": ("0", None), "pair": ("1", "pair"), "pairw": ("1", "pairw"), "ws2": ("0", "ws2"), "ws4": ("0", "ws4")}
 
 
 def set_form(name):
