@@ -249,6 +249,8 @@ class TorchVectorMnkEnv:
     # ------------------------------------------------------------------ reference surface
     def reset(self, env_indices: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """reference env:34-44"""
+        if self.num_envs == 0:  # nothing to reset; zero-element tensors have no storage to point at
+            return self.observe()
         if env_indices is None:
             mnk_hip.call("mnk_reset_all", mnk_hip.ptr(self._planes), mnk_hip.ptr(self._meta), self.num_envs,
                          self.words, self._stream())

@@ -478,3 +478,39 @@ print("EMIT_OK")
     env = dict(os.environ, MNK_EMIT_THREADS="512", MNK_EMIT_ENVS="48")
     out = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=300)
     assert "EMIT_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_empty_and_single_env_batches(hip):
+    """Edge sizes: an env with no envs at all is a no-op everywhere (the reference's tensors simply have a zero
+    dimension), and one env works like any other batch."""
+    from selfplay.policy import RandomPolicy
+    from selfplay.torch_self_play_wrapper import TorchSelfPlayWrapper
+
+    env = hip.Env(9, 9, 5, 0, device=DEV)
+    obs = env.reset()
+    assert obs["observation"].shape == (0, 2, 9, 9) and obs["action_mask"].shape == (0, 81)
+    o, r, d = env.step(torch.zeros(0, dtype=torch.long, device=DEV))
+    assert r.shape == (0,) and d.shape == (0,) and o["action_mask"].dtype == torch.bool
+    o, r, d = env.step_subset(torch.zeros(0, dtype=torch.long, device=DEV), torch.zeros(0, dtype=torch.long, device=DEV))
+    assert r.shape == (0,)
+    env.reset(torch.zeros(0, dtype=torch.long, device=DEV))
+    rec = hip.Rollout(env, seed=1).run(16)
+    assert rec.planes.shape == (16, 3, 0) and rec.meta.shape == (16, 0)
+    wrap = TorchSelfPlayWrapper(env, seed=1)
+    wrap.set_opponent(RandomPolicy(81, seed=2))
+    o, _ = wrap.reset()
+    o, r, t, tr, _ = wrap.step(torch.zeros(0, dtype=torch.long, device=DEV))
+    assert r.shape == (0,) and t.shape == (0,) and tr.shape == (0,)
+    assert RandomPolicy(81, seed=3).act(o).shape == (0,)
+    env.check_errors()
+
+    one, ora = hip.Env(9, 9, 5, 1, device=DEV), OracleVectorEnv(9, 9, 5, 1)
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        a = torch.from_numpy(rng.integers(0, 81, 1))
+        o1, r1, d1 = one.step(a.to(DEV))
+        o2, r2, d2 = ora.step(a)
+        assert torch.equal(o1["observation"].cpu(), o2["observation"]) and torch.equal(r1.cpu(), r2) and torch.equal(d1.cpu(), d2)
+        if bool(d2.any()):
+            one.reset(torch.tensor([0], device=DEV))
+            ora.reset(torch.tensor([0]))
