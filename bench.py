@@ -190,11 +190,12 @@ def api_path_rate(env, seed, steps=200):
     return steps * n / (time.perf_counter() - t0)
 
 
-def api_path_graphed_rate(env, seed, plies_per_graph=64, replays=8):
+def api_path_graphed_rate(env, seed, plies_per_graph=64, replays=8, fused_reset=False):
     """BASELINE config 2 as the API would be driven in production: the same three launches per ply
     (mnk_sample_legal -> mnk_step with the legal mask -> mnk_reset_mask), ``plies_per_graph`` plies captured
     once into a hipGraph (torch.cuda.graph) and replayed -- the Philox step counter advances in device memory
-    (``step_dev``), so every replay plays new plies.  No host launch cost per ply: what is left is the kernels."""
+    (``step_dev``), so every replay plays new plies.  No host launch cost per ply: what is left is the kernels.
+    ``fused_reset``: two launches per ply, the reset of finished games folded into mnk_step (MNK_STEP_AUTORESET)."""
     n, dev = env.num_envs, env._dev
     acts = torch.empty(n, dtype=torch.long, device=dev)
     rew = torch.empty(n, dtype=torch.float32, device=dev)
@@ -205,8 +206,9 @@ def api_path_graphed_rate(env, seed, plies_per_graph=64, replays=8):
     def body():
         for t in range(plies_per_graph):
             env.sample_legal_into(acts, seed=seed, step=t, step_dev=step_dev)
-            env.step_into(acts, rew, done, mask)
-            env.reset_mask_(done)
+            env.step_into(acts, rew, done, mask, autoreset=fused_reset)
+            if not fused_reset:
+                env.reset_mask_(done)
         step_dev.add_(plies_per_graph)
 
     side = torch.cuda.Stream(dev)
@@ -649,6 +651,7 @@ def main():
         if world == 1 and not args.no_api_path:
             out["api_path_env_steps_per_s"] = api_path_rate(env, args.seed)
             out["api_path_graphed_env_steps_per_s"] = api_path_graphed_rate(env, args.seed)
+            out["api_path_graphed_fused_reset_env_steps_per_s"] = api_path_graphed_rate(env, args.seed, fused_reset=True)
             out["replay_env_steps_per_s"] = replay_rate(env, roll, chunk)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(env, args.cpu_seconds, args.cpu_threads)

@@ -65,6 +65,9 @@ extern "C" {
 
 /* flags for mnk_step and the mnk_selfplay_* functions */
 #define MNK_STEP_STRICT 1u /* refuse moves onto occupied cells (the behaviour tests/test_mnk_integration.py:68-81 expects) */
+#define MNK_STEP_AUTORESET 2u /* mnk_step, full batch only: an env whose game this ply finished is reset in the same launch
+                               * (env.reset(nonzero(done)), env/torch_vector_mnk_env.py:34-44) and the legal mask / observation
+                               * written are those of the fresh board -- the raw loop "step; reset(done); observe" in one launch */
 
 /* element type of the logits handed to mnk_sample_logits */
 #define MNK_LOGITS_F32 0

@@ -44,6 +44,7 @@ k_step_full(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_
     MnkEnv<NW> e;
     env_load<NW>(e, planes, meta, N, g.W, i);
     MnkPly ply = env_play<NW, CN, CK>(g, e, actions[i], (flags & MNK_STEP_STRICT) != 0);
+    if ((flags & MNK_STEP_AUTORESET) && ply.done) env_clear<NW>(e);  // :34-44 for the envs of nonzero(done)
     if (ply.err) mnk_report(err, ply.err, i);
     else env_store<NW>(e, planes, meta, N, g.W, i);
     rewards[i] = ply.win ? 1.0f : 0.0f;   // :75-77
@@ -574,6 +575,7 @@ int mnk_step(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, c
   if (rc != MNK_OK) return rc;
   if (!planes || !meta || !rewards || !dones || N < 0 || A < 0 || (A > 0 && !actions)) return MNK_EINVAL;
   if (!active_idx && A != N) return MNK_EINVAL;
+  if (active_idx && (flags & MNK_STEP_AUTORESET)) return MNK_EINVAL;
   if (N == 0) return MNK_OK;
   hipStream_t s = (hipStream_t)stream;
   if (!active_idx) {

@@ -308,14 +308,16 @@ class TorchVectorMnkEnv:
         return {"observation": obs, "action_mask": mask}, rewards, dones
 
     # ------------------------------------------------------------------ buffer-reusing forms (graph-capturable)
-    def step_into(self, actions, rewards, dones, mask=None, obs=None) -> None:
+    def step_into(self, actions, rewards, dones, mask=None, obs=None, autoreset: bool = False) -> None:
         """``step`` into caller-owned buffers; ``mask`` / ``obs`` may be None to skip them.
-        One kernel launch, nothing allocated, nothing synchronised (unless ``strict``)."""
+        One kernel launch, nothing allocated, nothing synchronised (unless ``strict``).
+        ``autoreset``: finished games restart in the same launch and ``mask`` / ``obs`` show the fresh boards --
+        ``step(a); reset(nonzero(done)); observe()`` of the raw loop as one kernel."""
         if self.num_envs:
             mnk_hip.call("mnk_step", mnk_hip.ptr(self._planes), mnk_hip.ptr(self._meta), self.num_envs, self.m,
                          self.n, self.k, mnk_hip.ptr(actions), None, self.num_envs, mnk_hip.ptr(rewards),
                          mnk_hip.ptr(dones), mnk_hip.ptr(mask), mnk_hip.ptr(obs), mnk_hip.ptr(self._err),
-                         self._flags(), self._stream())
+                         self._flags() | (mnk_hip.STEP_AUTORESET if autoreset else 0), self._stream())
         if self.strict:
             self.check_errors()
 

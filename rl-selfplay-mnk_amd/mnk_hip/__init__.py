@@ -15,7 +15,7 @@ ABI_VERSION = 3
 
 MNK_OK = 0
 ERR_NONE, ERR_ACTION_RANGE, ERR_ILLEGAL_MOVE = 0, 1, 2
-STEP_STRICT = 1
+STEP_STRICT, STEP_AUTORESET = 1, 2
 LOGITS_F32, LOGITS_BF16 = 0, 1
 COMM_ID_BYTES = 128
 SP_NEED_OPP, SP_WAS_RESET = 1, 2

@@ -514,3 +514,37 @@ def test_empty_and_single_env_batches(hip):
         if bool(d2.any()):
             one.reset(torch.tensor([0], device=DEV))
             ora.reset(torch.tensor([0]))
+
+
+@pytest.mark.parametrize("m,n,k,nenv", [(3, 3, 3, 300), (9, 9, 5, 130), (7, 9, 7, 64)])
+def test_step_with_autoreset_equals_step_reset_observe(hip, m, n, k, nenv):
+    """MNK_STEP_AUTORESET: one launch == the raw loop's step(a); reset(nonzero(done)); observe() on the oracle
+    (env:55-84, :34-44, :46-53): rewards / dones of the ply, state and mask / observation of the restarted games."""
+    env, ora = hip.Env(m, n, k, nenv, device=DEV), OracleVectorEnv(m, n, k, nenv)
+    rng = np.random.default_rng(m * n)
+    acts = torch.empty(nenv, dtype=torch.long, device=DEV)
+    rew = torch.empty(nenv, dtype=torch.float32, device=DEV)
+    done = torch.empty(nenv, dtype=torch.bool, device=DEV)
+    mask = torch.empty((nenv, m * n), dtype=torch.bool, device=DEV)
+    obs = torch.empty((nenv, 2, m, n), dtype=torch.float32, device=DEV)
+    finished = 0
+    want = ora.observe()
+    for t in range(4 * m * n):
+        legal = want["action_mask"].numpy()
+        a = np.array([rng.choice(np.nonzero(row)[0]) for row in legal])
+        acts.copy_(torch.from_numpy(a))
+        env.step_into(acts, rew, done, mask, obs, autoreset=True)
+        _, r2, d2 = ora.step(torch.from_numpy(a))
+        if bool(d2.any()):
+            ora.reset(torch.nonzero(d2).squeeze(1))
+        want = ora.observe()
+        finished += int(d2.sum())
+        assert torch.equal(rew.cpu(), r2) and torch.equal(done.cpu(), d2), t
+        assert torch.equal(mask.cpu(), want["action_mask"]) and torch.equal(obs.cpu(), want["observation"]), t
+        assert torch.equal(env.move_counts.cpu(), ora.move_counts) and torch.equal(env.current_player.cpu(), ora.current_player)
+    assert finished > nenv
+    with pytest.raises(hip.lib.MnkHipError):  # subset steps have no autoreset form
+        idx = torch.arange(4, device=DEV)
+        hip.lib.call("mnk_step", hip.lib.ptr(env._planes), hip.lib.ptr(env._meta), nenv, m, n, k, hip.lib.ptr(acts[:4].contiguous()),
+                     hip.lib.ptr(idx), 4, hip.lib.ptr(rew), hip.lib.ptr(done), None, None, hip.lib.ptr(env._err),
+                     hip.lib.STEP_AUTORESET, env._stream())
