@@ -1,45 +1,52 @@
-"""Agent-vs-benchmark validation on the HIP env (``/root/reference/src/selfplay/validation.py:6-44``).
+"""Agent-vs-benchmark validation on the HIP env -- the caller the reference has in
+``/root/reference/src/selfplay/validation.py:6-44`` (``validate_gpu``), same arguments, same result keys.
 
-Same games, same bookkeeping (first terminal reward of every env, half the envs as black and
-half as white, W/L/D by exact comparison with +-1.0 / 0.0), same result keys.  The reference
-polls ``active_mask.any()`` on the host after every step; a game here ends within
-ceil(m*n/2) + 1 agent steps, so the loop runs that fixed number of steps with the accumulators
-on the device and synchronises once at the end.
+What the reference computes: ``n_episodes`` envs, the first half with the agent as black and the second half as
+white (:14-15), one game per env -- the reward of the step that first terminates an env is that env's result
+(:28-32) -- and the shares of +1 / -1 / 0 results (:34-44).  It polls ``active_mask.any()`` on the host after every
+step.  A game ends within ceil(m*n/2) + 1 agent steps, so here the loop has that fixed length, the per-env results
+accumulate on the device, and the host synchronises once, when it reads the three counts.
 """
 import torch
 
 from env.torch_vector_mnk_env import TorchVectorMnkEnv
 from selfplay.torch_self_play_wrapper import TorchSelfPlayWrapper
 
+_KEY = "validation/vs_benchmark/"
+
+
+def first_episode_results(wrapper, agent_policy, obs, max_agent_steps: int):
+    """Plays ``max_agent_steps`` steps from ``obs`` and returns, per env, the reward of the step that first
+    terminated it (f32 [N]: +1 win, -1 loss, 0 draw) and a bool [N] that is still set where no game ended.  Envs
+    restart after their first game (autoreset) and keep playing; those later games do not count.  No host
+    synchronisation."""
+    n = wrapper.num_envs
+    result = torch.zeros(n, dtype=torch.float32, device=wrapper._dev)
+    open_games = torch.ones(n, dtype=torch.bool, device=wrapper._dev)
+    for _ in range(max_agent_steps):
+        with torch.no_grad():
+            actions = agent_policy.act(obs, deterministic=False)  # validation.py:24
+        obs, rewards, terminated, _, _ = wrapper.step(actions)
+        result = torch.where(open_games & terminated, rewards, result)
+        open_games &= ~terminated
+    return result, open_games
+
 
 def validate_gpu(agent_policy, opponent_policy, mnk_config, n_episodes=1024, device="cuda"):
     m, n, k = mnk_config
-    val_env = TorchVectorMnkEnv(m, n, k, num_envs=n_episodes, device=device)
-    wrapper = TorchSelfPlayWrapper(val_env)
+    wrapper = TorchSelfPlayWrapper(TorchVectorMnkEnv(m, n, k, num_envs=n_episodes, device=device))
     wrapper.set_opponent(opponent_policy)
-
-    agent_sides = torch.zeros(n_episodes, dtype=torch.long, device=device)
-    agent_sides[n_episodes // 2:] = 1  # validation.py:14-15
-    obs, _ = wrapper.reset(options={"agent_side": agent_sides})
-
-    finished_rewards = torch.zeros(n_episodes, device=device)
-    active = torch.ones(n_episodes, dtype=torch.bool, device=device)
-    for _ in range((m * n + 1) // 2 + 1):
-        with torch.no_grad():
-            actions = agent_policy.act(obs, deterministic=False)
-        obs, rewards, terminated, _, _ = wrapper.step(actions)
-        just_finished = terminated & active
-        finished_rewards = torch.where(just_finished, rewards, finished_rewards)
-        active = active & ~terminated
-    assert not bool(active.any()), "a game outlived ceil(m*n/2)+1 agent steps"
-
-    wins = (finished_rewards == 1.0).sum().item()
-    losses = (finished_rewards == -1.0).sum().item()
-    draws = (finished_rewards == 0.0).sum().item()
+    sides = (torch.arange(n_episodes, device=device) >= n_episodes // 2).to(torch.long)  # black first, then white
+    obs, _ = wrapper.reset(options={"agent_side": sides})
+    result, unfinished = first_episode_results(wrapper, agent_policy, obs, (m * n + 1) // 2 + 1)
+    counts = [(result == x).sum() for x in (1.0, -1.0, 0.0)] + [unfinished.sum()]
+    wins, losses, draws, still_open = (int(v) for v in torch.stack(counts).tolist())  # the one synchronisation
+    if still_open:
+        raise RuntimeError("validate_gpu: a game outlived ceil(m*n/2)+1 agent steps")
     return {
-        "validation/vs_benchmark/win_rate": wins / n_episodes,
-        "validation/vs_benchmark/loss_rate": losses / n_episodes,
-        "validation/vs_benchmark/draw_rate": draws / n_episodes,
-        "validation/vs_benchmark/score_rate": (wins + 0.5 * draws) / n_episodes,
-        "validation/vs_benchmark/games_played": n_episodes,
+        _KEY + "win_rate": wins / n_episodes,
+        _KEY + "loss_rate": losses / n_episodes,
+        _KEY + "draw_rate": draws / n_episodes,
+        _KEY + "score_rate": (wins + 0.5 * draws) / n_episodes,
+        _KEY + "games_played": n_episodes,
     }
