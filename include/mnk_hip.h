@@ -214,7 +214,8 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
 /* Boards other than 3x3x3, 9x9x5, 13x13x5, 15x15x5 and 19x19x5 have no ahead-of-time specialisation of the rollout
  * kernel; mnk_rollout_random compiles one with hiprtc (about a second, once per board / record / log-width
  * combination and process) when a launch covers at least 2^20 env-steps -- environment MNK_JIT=1: always, MNK_JIT=0:
- * never (the kernels with run-time geometry then run, 3-5x slower).  Results are identical either way.
+ * never (the kernels with run-time geometry then run, 3-5x slower).  Results are identical either way.  The first
+ * such launch compiles and loads a code object: make it outside a hipGraph capture (later launches only enqueue).
  * mnk_jit_compile_rollout only compiles (no GPU needed): code object bytes, or a negative status with the
  * compiler's log in mnk_jit_last_error(). */
 int64_t mnk_jit_compile_rollout(int m, int n, int k, int record, int act_bytes);

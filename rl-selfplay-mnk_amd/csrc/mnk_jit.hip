@@ -29,7 +29,7 @@ struct Compiled {
 };
 
 std::mutex g_mu;
-std::map<std::tuple<int, int, int, int, int>, Compiled> g_cache;
+std::map<std::tuple<int, int, int, int, int, int>, Compiled> g_cache;  // (device, m, n, k, record, log width)
 thread_local char g_jit_err[2048] = "";
 
 // compiles the rollout kernel for this geometry; code object bytes in `code` (no GPU needed for this part)
@@ -70,8 +70,10 @@ bool compile(const MnkGeom& g, bool rec, int act, std::vector<char>& code) {
 // kernel of this geometry, compiled on first use; nullptr (and mnk_jit_last_error) when that failed -- the caller
 // then stays on the ahead-of-time generic kernel
 hipFunction_t mnk_jit_rollout_function(const MnkGeom& g, bool rec, int act) {
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return nullptr;  // a code object is loaded into one device's context
   std::lock_guard<std::mutex> lock(g_mu);
-  Compiled& c = g_cache[std::make_tuple(g.m, g.n, g.k, rec ? 1 : 0, act)];
+  Compiled& c = g_cache[std::make_tuple(device, g.m, g.n, g.k, rec ? 1 : 0, act)];
   if (c.fn || c.failed) return c.fn;
   std::vector<char> code;
   if (!compile(g, rec, act, code)) { c.failed = true; return nullptr; }
