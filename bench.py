@@ -41,6 +41,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 # bench.py cannot run rocprofv3 on itself; configurations without a committed profile report null.
 PMC_TRAFFIC = {
     ("9x9x5", 65536, 256): (474.67e6, "profiles/r02_rollout_9x9x5.md"),
+    ("19x19x5", 32768, 256): (845.85e6, "profiles/r02_rollout_19x19x5_32768.md"),   # two lanes per env, words split
+    ("12x12x5", 65536, 256): (745.25e6, "profiles/r02_rollout_12x12x5_jit.md"),     # run-time specialised kernel
 }
 
 
@@ -608,7 +610,8 @@ def main():
             "traffic_unit": "bytes per launch",
             "traffic_source": PMC_TRAFFIC.get((args.board, nenv, chunk), (None, None))[1],
             "alg_bytes_per_launch": alg_bytes,
-            "kernel": "k_rollout_random",
+            "kernel": "k_rollout_random (the launcher's form for this board and batch: one lane per env, two lanes per env, "
+                      "or the run-time specialised variant)",
             "launches": launches,
             "avg_launch_us": launch_s * 1e6,
             "alg_bytes_per_env_step": record_bytes(rows) + 2 * state_bytes(words) / plies_per_launch,

@@ -15,5 +15,5 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" --
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- python3 $B --steps 4 > "$OUT/write.json" 2> "$OUT/write.err"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE \
   --kernel-trace --output-format csv -d "$OUT/sq" -- python3 $B --steps 4 > "$OUT/sq.json" 2> "$OUT/sq.err"
-python3 "$R/tools/summarize_prof.py" "$OUT" "$TAG" > "$OUT/summary.md"
+python3 "$R/tools/summarize_prof.py" "$OUT" "$TAG" ${MNK_PROF_KERNEL:-k_rollout_random} > "$OUT/summary.md"
 cat "$OUT/summary.md"
