@@ -31,7 +31,7 @@ def main():
         print("| kernel | calls | total ns | average ns | % | min ns | max ns |")
         print("|---|---|---|---|---|---|---|")
         for r in list(csv.DictReader(open(f)))[:8]:
-            name = r["Name"].split("(")[0][:90]
+            name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0][:90]
             print(f"| `{name}` | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | "
                   f"{float(r['Percentage']):.2f} | {r['MinNs']} | {r['MaxNs']} |")
         print()
