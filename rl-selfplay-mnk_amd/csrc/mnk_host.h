@@ -109,6 +109,14 @@ inline int mnk_block_threads() {
 #define MNK_K(name) HIP_KERNEL_NAME(name<NW, CN, CK>)
 
 
+// may the one-lane rollout address its record stores with 32-bit lane offsets (SADDR form)?  Only while a wave is
+// alone on its SIMD (where it measured faster) and a launch's record rows stay below 4 GiB
+inline bool mnk_rollout_saddr_ok(const MnkGeom& g, int64_t N, int T) {
+  const char* v = getenv("MNK_ROLLOUT_SADDR");  // "0" switches the form off (A/B timing; read per call)
+  if (v && atoi(v) == 0) return false;
+  return N <= 65536 && ((int64_t)T * g.NW + 1) * N * 8 < (1ll << 32);
+}
+
 // one-lane rollout variants that write the action log (mnk_rollout_log.hip); act_bytes is 1 or 2
 void mnk_launch_rollout_log(const MnkGeom& g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed,
                             uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
@@ -126,7 +134,7 @@ void mnk_launch_rollout_ws(const MnkGeom& g, int ws, uint64_t* planes, uint32_t*
                            void* act_log, int act_bytes, void* stream);
 
 // run-time specialised rollout kernels (mnk_jit.hip, hiprtc): nullptr when the compile failed
-hipFunction_t mnk_jit_rollout_function(const MnkGeom& g, bool rec, int act);
+hipFunction_t mnk_jit_rollout_function(const MnkGeom& g, bool rec, int act, bool saddr);
 int mnk_jit_launch_rollout(hipFunction_t fn, MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed,
                            uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
                            void* act_log, void* stream);

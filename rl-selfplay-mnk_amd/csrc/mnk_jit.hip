@@ -29,11 +29,11 @@ struct Compiled {
 };
 
 std::mutex g_mu;
-std::map<std::tuple<int, int, int, int, int, int>, Compiled> g_cache;  // (device, m, n, k, record, log width)
+std::map<std::tuple<int, int, int, int, int, int, int>, Compiled> g_cache;  // (device, m, n, k, record, log width, saddr)
 thread_local char g_jit_err[2048] = "";
 
 // compiles the rollout kernel for this geometry; code object bytes in `code` (no GPU needed for this part)
-bool compile(const MnkGeom& g, bool rec, int act, std::vector<char>& code) {
+bool compile(const MnkGeom& g, bool rec, int act, bool saddr, std::vector<char>& code) {
   static const char* program =
       "#include \"mnk_rollout_lane.h\"\n";
   hiprtcProgram prog = nullptr;
@@ -44,9 +44,9 @@ bool compile(const MnkGeom& g, bool rec, int act, std::vector<char>& code) {
   }
   const std::string d_nw = "-DMNK_JIT_NW=" + std::to_string(g.NW), d_cn = "-DMNK_JIT_CN=" + std::to_string(g.n),
                     d_ck = "-DMNK_JIT_CK=" + std::to_string(g.k), d_rec = "-DMNK_JIT_REC=" + std::to_string(rec ? 1 : 0),
-                    d_act = "-DMNK_JIT_ACT=" + std::to_string(act);
+                    d_act = "-DMNK_JIT_ACT=" + std::to_string(act), d_sa = "-DMNK_JIT_SADDR=" + std::to_string(saddr ? 1 : 0);
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", d_nw.c_str(), d_cn.c_str(),
-                        d_ck.c_str(), d_rec.c_str(), d_act.c_str()};
+                        d_ck.c_str(), d_rec.c_str(), d_act.c_str(), d_sa.c_str()};
   const hiprtcResult rc = hiprtcCompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
   if (rc != HIPRTC_SUCCESS) {
     size_t n = 0;
@@ -69,14 +69,14 @@ bool compile(const MnkGeom& g, bool rec, int act, std::vector<char>& code) {
 
 // kernel of this geometry, compiled on first use; nullptr (and mnk_jit_last_error) when that failed -- the caller
 // then stays on the ahead-of-time generic kernel
-hipFunction_t mnk_jit_rollout_function(const MnkGeom& g, bool rec, int act) {
+hipFunction_t mnk_jit_rollout_function(const MnkGeom& g, bool rec, int act, bool saddr) {
   int device = 0;
   if (hipGetDevice(&device) != hipSuccess) return nullptr;  // a code object is loaded into one device's context
   std::lock_guard<std::mutex> lock(g_mu);
-  Compiled& c = g_cache[std::make_tuple(device, g.m, g.n, g.k, rec ? 1 : 0, act)];
+  Compiled& c = g_cache[std::make_tuple(device, g.m, g.n, g.k, rec ? 1 : 0, act, saddr ? 1 : 0)];
   if (c.fn || c.failed) return c.fn;
   std::vector<char> code;
-  if (!compile(g, rec, act, code)) { c.failed = true; return nullptr; }
+  if (!compile(g, rec, act, saddr, code)) { c.failed = true; return nullptr; }
   if (hipModuleLoadData(&c.module, code.data()) != hipSuccess ||
       hipModuleGetFunction(&c.fn, c.module, "mnk_jit_rollout") != hipSuccess) {
     snprintf(g_jit_err, sizeof(g_jit_err), "hipModuleLoadData / hipModuleGetFunction failed: %s",
@@ -111,7 +111,7 @@ int64_t mnk_jit_compile_rollout(int m, int n, int k, int record, int act_bytes) 
   if (rc != MNK_OK) return rc;
   if (act_bytes < 0 || act_bytes > 2) return MNK_EINVAL;
   std::vector<char> code;
-  if (!compile(g, record != 0, act_bytes, code)) return MNK_ELAUNCH;
+  if (!compile(g, record != 0, act_bytes, record != 0, code)) return MNK_ELAUNCH;  // the form a 65 536-env launch uses
   return (int64_t)code.size();
 }
 

@@ -75,7 +75,7 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
     const char* jit_env = getenv("MNK_JIT");
     const bool want = jit_env ? atoi(jit_env) != 0 : (N * (int64_t)T >= (1ll << 20));
     if (want) {
-      if (hipFunction_t fn = mnk_jit_rollout_function(g, rec, act_bytes))
+      if (hipFunction_t fn = mnk_jit_rollout_function(g, rec, act_bytes, rec && mnk_rollout_saddr_ok(g, N, T)))
         return mnk_jit_launch_rollout(fn, g, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,
                                       rec ? rec_meta : nullptr, stats, act_log, stream);
     }
@@ -98,6 +98,23 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   if (act_bytes) {
     mnk_launch_rollout_log(g, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,
                            rec ? rec_meta : nullptr, stats, act_log, act_bytes, stream);
+    return mnk_launch_status("rollout_random");
+  }
+  // Record stores as `uniform base + 32-bit lane offset` (SADDR, mnk_rollout_lane.h) while a wave is alone on its SIMD
+  // (N <= 65 536: the kernel is bound by its instruction count and this saves ~4 of ~150 per ply: 92.0 -> 88.5 us at
+  // the headline size) and one launch's record rows fit 32-bit offsets; from 131 072 envs up the kernel is bound by
+  // the HBM write rate and the 64-bit form measured faster (157 vs 166-184 us), so it stays there.
+  if (rec && pair_geom && mnk_rollout_saddr_ok(g, N, T)) {
+#define MNK_SADDR(NWv, CNv, CKv)                                                                                      \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NWv, CNv, CKv, true, 0, true>), grid, dim3(B), 0,               \
+                     (hipStream_t)stream, g, planes, meta, N, T, seed, step0, env_id0, rec_planes, rec_meta,          \
+                     (unsigned long long*)stats, act_log)
+    if (g.n == 9) MNK_SADDR(3, 9, 5);
+    else if (g.n == 3) MNK_SADDR(1, 3, 3);
+    else if (g.n == 13) MNK_SADDR(6, 13, 5);
+    else if (g.n == 15) MNK_SADDR(8, 15, 5);
+    else MNK_SADDR(12, 19, 5);
+#undef MNK_SADDR
     return mnk_launch_status("rollout_random");
   }
 #define MNK_ROLLOUT(REC)                                                                                       \

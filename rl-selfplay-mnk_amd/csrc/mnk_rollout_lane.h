@@ -27,7 +27,10 @@
 // (one 4-byte write, one s_barrier, one read per ply) and the record rows are split between the waves.  Move
 // selection and the state update are redundant.  Twice / four times the waves of the one-lane form: for batches
 // that leave SIMDs empty or alone with one wave, on boards whose scan dominates the ply (19x19).
-template <int NW, int CN, int CK, bool RECORD, int ACT = 0, bool PAIR = false, int WS = 1>
+// SADDR (one-lane form only): the record stores address `uniform base + 32-bit lane offset` (global_store ... s[base])
+// instead of a 64-bit pointer per lane -- two address instructions fewer per ply; one launch may then write at
+// most 4 GiB of record rows (the launcher checks).
+template <int NW, int CN, int CK, bool RECORD, int ACT = 0, bool PAIR = false, int WS = 1, bool SADDR = false>
 struct RolloutLane {
   static constexpr bool EXACT = CN != 0;
   const MnkGeom& g;
@@ -44,6 +47,9 @@ struct RolloutLane {
   uint64_t* rp = nullptr;  // rec_planes[t][0][i]
   uint32_t* rp32 = nullptr;  // PAIR: half `role` of rec_planes[t][0][i]
   uint32_t* rm = nullptr;  // rec_meta[t][i]
+  const char* rbase[SADDR ? NW : 1] = {};  // SADDR: rec_planes[.][w][0] / rec_meta as wave-uniform bases ...
+  const char* mbase = nullptr;
+  uint32_t roff = 0, moff = 0;  // ... and this lane's byte offsets of rec_planes[t][0][i] / rec_meta[t][i]
   uint8_t* ra = nullptr;   // act_log[t / 4][i]
   uint64_t quad = 0;       // the actions of the current group of four plies
   // per-lane statistics, one add each per ply (T <= 65535 per launch): draws = done - wins, black wins =
@@ -61,6 +67,13 @@ struct RolloutLane {
       if (PAIR) rp32 = (uint32_t*)(rec_planes + i) + role;
       else rp = rec_planes + i;
       rm = rec_meta + i;
+      if (SADDR) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) rbase[w] = (const char*)(rec_planes + (int64_t)w * N);
+        mbase = (const char*)rec_meta;
+        roff = (uint32_t)i * 8u;
+        moff = (uint32_t)i * 4u;
+      }
     }
     if (ACT) ra = (uint8_t*)act_log + i * 4 * ACT;
   }
@@ -110,6 +123,15 @@ struct RolloutLane {
             __builtin_nontemporal_store((uint64_t)cur[w] | ((uint64_t)oth[w] << 32), rp + (int64_t)w * N);
         }
       rp += (int64_t)NW * N;
+      return;
+    }
+    if constexpr (SADDR) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+        if (EXACT || w < g.NW)
+          __builtin_nontemporal_store((uint64_t)cur[w] | ((uint64_t)oth[w] << 32),
+                                      (uint64_t*)(rbase[w] + (uint64_t)roff));
+      roff += (uint32_t)g.NW * (uint32_t)N * 8u;
       return;
     }
 #pragma unroll
@@ -226,9 +248,14 @@ struct RolloutLane {
     }
     const uint32_t done = win | (moves >= (uint32_t)g.C ? 1u : 0u);   // :72-73
     if (RECORD) {
-      if (WS == 1 || wrole == WS - 1)
-        __builtin_nontemporal_store((uint32_t)a | (win << MNK_REC_REWARD_SHIFT) | (done << MNK_REC_DONE_BIT) | (side << MNK_REC_SIDE_BIT), rm);
-      rm += N;
+      const uint32_t mword = (uint32_t)a | (win << MNK_REC_REWARD_SHIFT) | (done << MNK_REC_DONE_BIT) | (side << MNK_REC_SIDE_BIT);
+      if constexpr (SADDR) {
+        __builtin_nontemporal_store(mword, (uint32_t*)(mbase + (uint64_t)moff));
+        moff += (uint32_t)N * 4u;
+      } else {
+        if (WS == 1 || wrole == WS - 1) __builtin_nontemporal_store(mword, rm);
+        rm += N;
+      }
     }
     acc_done += done;
     acc_win += win;
@@ -246,7 +273,7 @@ struct RolloutLane {
 };
 
 // the one-lane kernel's body: one wave of 64 envs per workgroup of 64 threads
-template <int NW, int CN, int CK, bool RECORD, int ACT>
+template <int NW, int CN, int CK, bool RECORD, int ACT, bool SADDR = false>
 __device__ __forceinline__ void rollout_random_body(const MnkGeom& g, uint64_t* planes, uint32_t* meta, int64_t N, int T,
                                                     uint64_t seed, uint64_t step0, int64_t env_id0,
                                                     uint64_t* rec_planes, uint32_t* rec_meta, unsigned long long* stats,
@@ -258,7 +285,7 @@ __device__ __forceinline__ void rollout_random_body(const MnkGeom& g, uint64_t* 
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) {
-    RolloutLane<NW, CN, CK, RECORD, ACT> L(g, N, i, rec_planes, rec_meta, act_log);
+    RolloutLane<NW, CN, CK, RECORD, ACT, false, 1, SADDR> L(g, N, i, rec_planes, rec_meta, act_log);
     L.load(planes, meta, i);
     const uint64_t env = (uint64_t)(env_id0 + i);
     int t = 0;
@@ -302,16 +329,16 @@ __device__ __forceinline__ void rollout_random_body(const MnkGeom& g, uint64_t* 
 extern "C" __global__ void __launch_bounds__(64)
 mnk_jit_rollout(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed, uint64_t step0,
                 int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, unsigned long long* stats, void* act_log) {
-  rollout_random_body<MNK_JIT_NW, MNK_JIT_CN, MNK_JIT_CK, MNK_JIT_REC != 0, MNK_JIT_ACT>(
+  rollout_random_body<MNK_JIT_NW, MNK_JIT_CN, MNK_JIT_CK, MNK_JIT_REC != 0, MNK_JIT_ACT, MNK_JIT_SADDR != 0>(
       g, planes, meta, N, T, seed, step0, env_id0, rec_planes, rec_meta, stats, act_log);
 }
 #else
-template <int NW, int CN, int CK, bool RECORD, int ACT>
+template <int NW, int CN, int CK, bool RECORD, int ACT, bool SADDR = false>
 __global__ void __launch_bounds__(64)
 k_rollout_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed, uint64_t step0,
                  int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, unsigned long long* stats,
                  void* act_log) {
-  rollout_random_body<NW, CN, CK, RECORD, ACT>(g, planes, meta, N, T, seed, step0, env_id0, rec_planes, rec_meta, stats,
-                                               act_log);
+  rollout_random_body<NW, CN, CK, RECORD, ACT, SADDR>(g, planes, meta, N, T, seed, step0, env_id0, rec_planes, rec_meta,
+                                                      stats, act_log);
 }
 #endif

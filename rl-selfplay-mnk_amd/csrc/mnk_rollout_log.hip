@@ -9,6 +9,30 @@ void mnk_launch_rollout_log(const MnkGeom& g, uint64_t* planes, uint32_t* meta, 
   const int B = 64;
   const dim3 grid((unsigned)((N + B - 1) / B));
   const bool rec = rec_planes && rec_meta;
+  // compile-time boards, records on, one wave per SIMD: 32-bit lane offsets for the record stores (see mnk_rollout.hip)
+  const bool fixed = (g.n == 9 && g.k == 5 && g.NW == 3) || (g.n == 3 && g.k == 3 && g.NW == 1) ||
+                     (g.n == 13 && g.k == 5 && g.NW == 6) || (g.n == 15 && g.k == 5 && g.NW == 8) ||
+                     (g.n == 19 && g.k == 5 && g.NW == 12);
+  if (rec && fixed && mnk_rollout_saddr_ok(g, N, T)) {
+#define MNK_SADDR(NWv, CNv, CKv, ACTB)                                                                                \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NWv, CNv, CKv, true, ACTB, true>), grid, dim3(B), 0,            \
+                     (hipStream_t)stream, g, planes, meta, N, T, seed, step0, env_id0, rec_planes, rec_meta,          \
+                     (unsigned long long*)stats, act_log)
+    if (g.n == 19) MNK_SADDR(12, 19, 5, 2);                      // 361 cells: two bytes per action
+    else if (act_bytes == 1) {
+      if (g.n == 9) MNK_SADDR(3, 9, 5, 1);
+      else if (g.n == 3) MNK_SADDR(1, 3, 3, 1);
+      else if (g.n == 13) MNK_SADDR(6, 13, 5, 1);
+      else MNK_SADDR(8, 15, 5, 1);
+    } else {
+      if (g.n == 9) MNK_SADDR(3, 9, 5, 2);
+      else if (g.n == 3) MNK_SADDR(1, 3, 3, 2);
+      else if (g.n == 13) MNK_SADDR(6, 13, 5, 2);
+      else MNK_SADDR(8, 15, 5, 2);
+    }
+#undef MNK_SADDR
+    return;
+  }
 #define MNK_ROLLOUT(REC, ACTB)                                                                                   \
   MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NW, CN, CK, REC, ACTB>), grid, dim3(B), 0, \
                                      (hipStream_t)stream, g, planes, meta, N, T, seed, step0, env_id0,           \
