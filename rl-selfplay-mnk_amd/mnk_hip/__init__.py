@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmnk_hip.so")
+# MNK_HIP_LIB: another build of the same library (A/B experiments with compile-time options); default: the in-tree build
+LIB_PATH = os.environ.get("MNK_HIP_LIB") or os.path.join(_HERE, "libmnk_hip.so")
 ABI_VERSION = 3
 
 MNK_OK = 0
