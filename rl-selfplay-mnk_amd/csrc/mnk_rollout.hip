@@ -85,7 +85,8 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   // directions); MNK_ROLLOUT_FORM=pair|pairw forces one (pairw at any batch size)
   const bool force_w = form && !strcmp(form, "pairw");
   const bool force_d = form && !strcmp(form, "pair");
-  if (mnk_rollout_pairw_supported(g) && (force_w || (use_pair && !force_d && g.n >= 13))) {
+  const bool w_fits = ((int64_t)T * g.NW + 1) * N * 8 < (1ll << 32);  // its record stores use 32-bit byte offsets
+  if (mnk_rollout_pairw_supported(g) && w_fits && (force_w || (use_pair && !force_d && g.n >= 13))) {
     mnk_launch_rollout_pairw(g, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,
                              rec ? rec_meta : nullptr, stats, act_log, act_bytes, stream);
     return mnk_launch_status("rollout_random_pairw");

@@ -31,8 +31,11 @@ struct RolloutPairW {
   uint32_t up_mask;  // role 0: all ones (the partner's words continue this lane's bit string), role 1: 0 (zeros above)
   uint32_t cur[H], oth[H], valid[H];
   uint32_t side, moves, moves_in = 0;
-  uint64_t* rp = nullptr;  // rec_planes[t][role*H][i]
-  uint32_t* rm = nullptr;  // rec_meta[t][i]
+  // record stores address `wave-uniform row base + this lane's 32-bit byte offset` (global_store ... s[base]): one
+  // 32-bit add per ply instead of a 64-bit pointer per row; the launcher keeps a launch's record rows below 4 GiB
+  const char* rbase[H] = {};  // rec_planes[.][j][0]
+  const char* mbase = nullptr;
+  uint32_t roff = 0, moff = 0;  // byte offsets of rec_planes[t][role*H][i] (relative to row 0) / rec_meta[t][i]
   uint8_t* ra = nullptr;   // act_log[t / 4][i]
   uint64_t quad = 0;
   uint32_t acc_done = 0, acc_win = 0, acc_white = 0;
@@ -41,8 +44,11 @@ struct RolloutPairW {
                                           uint32_t* rec_meta, void* act_log)
       : g(g_), N(N_), role(role_), up_mask(role_ ? 0u : ~0u) {
     if (RECORD) {
-      rp = rec_planes + (int64_t)role * H * N + i;
-      rm = rec_meta + i;
+#pragma unroll
+      for (int j = 0; j < H; ++j) rbase[j] = (const char*)(rec_planes + (int64_t)j * N);
+      mbase = (const char*)rec_meta;
+      roff = ((uint32_t)i + role * (uint32_t)H * (uint32_t)N) * 8u;
+      moff = (uint32_t)i * 4u;
     }
     if (ACT) ra = (uint8_t*)act_log + i * 4 * ACT;
 #pragma unroll
@@ -196,8 +202,8 @@ struct RolloutPairW {
 #pragma unroll
       for (int j = 0; j < H; ++j)
         if (2 * H == NW || j + 1 < H || role == 0)  // odd NW: the upper lane's last word is padding, not a row
-          __builtin_nontemporal_store((uint64_t)cur[j] | ((uint64_t)oth[j] << 32), rp + (int64_t)j * N);
-      rp += (int64_t)NW * N;
+          __builtin_nontemporal_store((uint64_t)cur[j] | ((uint64_t)oth[j] << 32), (uint64_t*)(rbase[j] + (uint64_t)roff));
+      roff += (uint32_t)NW * (uint32_t)N * 8u;
     }
 #pragma unroll
     for (int j = 0; j < H; ++j) cur[j] |= hot[j];                         // env:68
@@ -208,8 +214,9 @@ struct RolloutPairW {
     const uint32_t done = win | (moves >= (uint32_t)g.C ? 1u : 0u);       // :72-73
     if (RECORD) {
       if (role == 0)
-        __builtin_nontemporal_store((uint32_t)a | (win << MNK_REC_REWARD_SHIFT) | (done << MNK_REC_DONE_BIT) | (side << MNK_REC_SIDE_BIT), rm);
-      rm += N;
+        __builtin_nontemporal_store((uint32_t)a | (win << MNK_REC_REWARD_SHIFT) | (done << MNK_REC_DONE_BIT) | (side << MNK_REC_SIDE_BIT),
+                                    (uint32_t*)(mbase + (uint64_t)moff));
+      moff += (uint32_t)N * 4u;
     }
     acc_done += done;
     acc_win += win;
