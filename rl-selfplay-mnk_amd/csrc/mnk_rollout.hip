@@ -55,7 +55,8 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   const bool pair_geom = (g.n == 9 && g.k == 5 && g.NW == 3) || (g.n == 3 && g.k == 3 && g.NW == 1) ||
                          (g.n == 13 && g.k == 5 && g.NW == 6) || (g.n == 15 && g.k == 5 && g.NW == 8) ||
                          (g.n == 19 && g.k == 5 && g.NW == 12);
-  const bool use_pair = pair_geom &&
+  const bool w_fits = ((int64_t)T * g.NW + 1) * N * 8 < (1ll << 32);  // the two-lane forms' record stores use 32-bit byte offsets
+  const bool use_pair = pair_geom && w_fits &&
                         (pair_override >= 0 ? pair_override != 0 : N <= 32768);
   const bool rec = rec_planes && rec_meta;
   // MNK_ROLLOUT_FORM=lane|pair|ws2|ws4 forces a kernel form (read per call: A/B timing, parity tests of every form)
@@ -85,7 +86,6 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   // directions); MNK_ROLLOUT_FORM=pair|pairw forces one (pairw at any batch size)
   const bool force_w = form && !strcmp(form, "pairw");
   const bool force_d = form && !strcmp(form, "pair");
-  const bool w_fits = ((int64_t)T * g.NW + 1) * N * 8 < (1ll << 32);  // its record stores use 32-bit byte offsets
   if (mnk_rollout_pairw_supported(g) && w_fits && (force_w || (use_pair && !force_d && g.n >= 13))) {
     mnk_launch_rollout_pairw(g, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,
                              rec ? rec_meta : nullptr, stats, act_log, act_bytes, stream);

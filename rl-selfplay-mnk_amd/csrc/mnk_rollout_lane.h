@@ -45,9 +45,9 @@ struct RolloutLane {
   uint32_t wrole = 0;      // WS > 1: this wave's index in its workgroup (wave-uniform)
   uint32_t* vx = nullptr;  // WS > 1: LDS verdicts u32[2][64][WS] (double-buffered by ply parity)
   uint64_t* rp = nullptr;  // rec_planes[t][0][i]
-  uint32_t* rp32 = nullptr;  // PAIR: half `role` of rec_planes[t][0][i]
   uint32_t* rm = nullptr;  // rec_meta[t][i]
-  const char* rbase[SADDR ? NW : 1] = {};  // SADDR: rec_planes[.][w][0] / rec_meta as wave-uniform bases ...
+  static constexpr bool OFF32 = SADDR || PAIR;  // the two-lane form always addresses its records this way
+  const char* rbase[OFF32 ? NW : 1] = {};  // SADDR / PAIR: rec_planes[.][w][0] / rec_meta as wave-uniform bases ...
   const char* mbase = nullptr;
   uint32_t roff = 0, moff = 0;  // ... and this lane's byte offsets of rec_planes[t][0][i] / rec_meta[t][i]
   uint8_t* ra = nullptr;   // act_log[t / 4][i]
@@ -64,14 +64,13 @@ struct RolloutLane {
                                          uint32_t* vx_ = nullptr)
       : g(g_), N(N_), role(role_), wrole(wrole_), vx(vx_) {
     if (RECORD) {
-      if (PAIR) rp32 = (uint32_t*)(rec_planes + i) + role;
-      else rp = rec_planes + i;
+      if (!PAIR) rp = rec_planes + i;
       rm = rec_meta + i;
-      if (SADDR) {
+      if (OFF32) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) rbase[w] = (const char*)(rec_planes + (int64_t)w * N);
         mbase = (const char*)rec_meta;
-        roff = (uint32_t)i * 8u;
+        roff = (uint32_t)i * 8u + (PAIR ? role * 4u : 0u);  // PAIR: lane `role` writes half `role` of every row
         moff = (uint32_t)i * 4u;
       }
     }
@@ -109,8 +108,9 @@ struct RolloutLane {
   __device__ __forceinline__ void store_record() {
     if constexpr (PAIR) {  // lane 0 writes the mover's word of every row, lane 1 the other side's: 256 B per wave and store
 #pragma unroll
-      for (int w = 0; w < NW; ++w) __builtin_nontemporal_store(role ? oth[w] : cur[w], rp32 + (int64_t)w * 2 * N);
-      rp32 += (int64_t)NW * 2 * N;
+      for (int w = 0; w < NW; ++w)
+        __builtin_nontemporal_store(role ? oth[w] : cur[w], (uint32_t*)(rbase[w] + (uint64_t)roff));
+      roff += (uint32_t)NW * (uint32_t)N * 8u;
       return;
     }
     if constexpr (WS > 1) {  // wave r writes rows [r*NW/WS, (r+1)*NW/WS): one taken uniform branch per ply
@@ -249,7 +249,7 @@ struct RolloutLane {
     const uint32_t done = win | (moves >= (uint32_t)g.C ? 1u : 0u);   // :72-73
     if (RECORD) {
       const uint32_t mword = (uint32_t)a | (win << MNK_REC_REWARD_SHIFT) | (done << MNK_REC_DONE_BIT) | (side << MNK_REC_SIDE_BIT);
-      if constexpr (SADDR) {
+      if constexpr (OFF32) {
         __builtin_nontemporal_store(mword, (uint32_t*)(mbase + (uint64_t)moff));
         moff += (uint32_t)N * 4u;
       } else {
