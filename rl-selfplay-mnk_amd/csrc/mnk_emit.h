@@ -21,14 +21,20 @@ struct MnkStage {
   uint32_t* tab_mask; // [C]
 };
 
+// row stride of the stage in words: B + 1, not B.  With B = 64 = the number of LDS banks, word w of env e sat in bank
+// e for every w, and the write-out -- where the lanes of a wave read a handful of DIFFERENT words of the SAME one or two
+// envs -- serialised 5-way (9x9) to 8-way (19x19) on that one bank.  With the odd stride word w of env e sits in bank
+// (w + e) mod 64: different words, different banks; lanes that want the same word are a broadcast.
+__host__ __device__ inline int mnk_stage_stride(int B) { return B + 1; }
+
 __host__ __device__ inline size_t mnk_stage_bytes(int NW, int C, int B) {
-  return (size_t)3 * NW * B * 4 + (size_t)3 * C * 4;
+  return (size_t)3 * NW * mnk_stage_stride(B) * 4 + (size_t)3 * C * 4;
 }
 
 __device__ __forceinline__ MnkStage mnk_stage_carve(void* lds, const MnkGeom& g, int B) {
   MnkStage s;
   s.words = (uint32_t*)lds;
-  s.tab_obs = s.words + (size_t)3 * g.NW * B;
+  s.tab_obs = s.words + (size_t)3 * g.NW * mnk_stage_stride(B);
   s.tab_mask = s.tab_obs + 2 * g.C;
   return s;
 }
@@ -39,7 +45,7 @@ __device__ __forceinline__ void mnk_stage_tables(const MnkStage& s, const MnkGeo
     const uint32_t cell = (uint32_t)(r - plane * g.C);
     const uint32_t bit = cell + mnk_div(cell, g.magic_n);
     const uint32_t wq = (uint32_t)(plane * g.NW) + (bit >> 5);
-    const uint32_t entry = ((wq * (uint32_t)B) << 5) | (bit & 31u);
+    const uint32_t entry = ((wq * (uint32_t)mnk_stage_stride(B)) << 5) | (bit & 31u);
     s.tab_obs[r] = entry;  // tab_mask aliases tab_obs + 2C
   }
 }
@@ -60,9 +66,10 @@ __device__ __forceinline__ void mnk_stage_put(const MnkStage& s, const MnkGeom& 
 #pragma unroll
   for (int w = 0; w < NW; ++w) {
     if (w < g.NW) {
-      s.words[(0 * g.NW + w) * B + el] = ch0[w];
-      s.words[(1 * g.NW + w) * B + el] = ch1[w];
-      s.words[(2 * g.NW + w) * B + el] = legal[w];
+      const int S = mnk_stage_stride(B);
+      s.words[(0 * g.NW + w) * S + el] = ch0[w];
+      s.words[(1 * g.NW + w) * S + el] = ch1[w];
+      s.words[(2 * g.NW + w) * S + el] = legal[w];
     }
   }
 }
