@@ -12,11 +12,11 @@
 #pragma once
 #include "mnk_device.h"
 
-// LDS image: u32 stage[3*NW][B] followed by u32 tab_obs[2C] and u32 tab_mask[C].
-// A table entry = (index of the word for env 0) << 5 | bit-in-word; lanes that expand
-// neighbouring cells read the same or adjacent words: broadcast or conflict-free.
+// LDS image: u32 stage[3*NW][B + 1] (odd row stride, see mnk_stage_stride) followed by u32 tab_obs[2C] and
+// u32 tab_mask[C].  A table entry = (index of the word for env 0) << 5 | bit-in-word; lanes that expand
+// neighbouring cells read the same word (a broadcast) or words of different rows (different banks).
 struct MnkStage {
-  uint32_t* words;    // [3*NW][B]
+  uint32_t* words;    // [3*NW][B + 1]
   uint32_t* tab_obs;  // [2C]
   uint32_t* tab_mask; // [C]
 };
