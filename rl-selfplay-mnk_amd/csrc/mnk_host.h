@@ -62,16 +62,18 @@ inline int mnk_launch_status(const char* what) {
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
-// workgroup size for kernels with a write-out stage (envs per workgroup)
-inline int mnk_block_envs(int64_t N) {
-  (void)N;
-  static int cached = 0;
-  if (!cached) {
+// envs per workgroup of the kernels with a write-out stage; `items` = envs (x plies for mnk_unpack_records) of the launch.
+// 64 by default; 32 while that still leaves fewer than 1 024 workgroups (19x19x5 x 32 768 envs: 25.5 vs 26.9 us for
+// the fused self-play step, tools/exp_kernels.py).  MNK_EMIT_ENVS=16|32|64 forces one (read once per process).
+inline int mnk_block_envs(int64_t items) {
+  static int forced = -1;
+  if (forced < 0) {
     const char* v = getenv("MNK_EMIT_ENVS");
-    int t = v ? atoi(v) : 64;
-    cached = (t == 16 || t == 32 || t == 64) ? t : 64;
+    const int t = v ? atoi(v) : 0;
+    forced = (t == 16 || t == 32 || t == 64) ? t : 0;
   }
-  return cached;
+  if (forced) return forced;
+  return items <= 32768 ? 32 : 64;
 }
 
 // threads per workgroup of those kernels: the first 64 lanes play their envs, then all waves of

@@ -691,7 +691,7 @@ int mnk_unpack_records(const uint64_t* rec_planes, const uint32_t* rec_meta, int
   if (rc != MNK_OK) return rc;
   if (!rec_meta || N < 0 || T < 0 || T > 65535 || ((obs || masks) && !rec_planes)) return MNK_EINVAL;
   if (N == 0 || T == 0) return MNK_OK;
-  const int B = mnk_block_envs(N);
+  const int B = mnk_block_envs(N * (int64_t)T);
   const bool emit = obs || masks;
   // slabs start at row t*N + env0: 16-byte alignment of every slab needs N*rowbytes % 16 == 0 too
   const bool obs_vec = aligned16(obs) && ((N * 2 * g.C * 4) % 16 == 0);
