@@ -548,3 +548,20 @@ def test_step_with_autoreset_equals_step_reset_observe(hip, m, n, k, nenv):
         hip.lib.call("mnk_step", hip.lib.ptr(env._planes), hip.lib.ptr(env._meta), nenv, m, n, k, hip.lib.ptr(acts[:4].contiguous()),
                      hip.lib.ptr(idx), 4, hip.lib.ptr(rew), hip.lib.ptr(done), None, None, hip.lib.ptr(env._err),
                      hip.lib.STEP_AUTORESET, env._stream())
+
+
+def test_long_launch_falls_back_to_64_bit_record_addresses(hip):
+    """Up to 65 536 envs the record stores use 32-bit byte offsets, valid while one launch's record rows stay below
+    4 GiB (9x9x5 x 65 536 envs: 2 730 plies).  A longer launch must take the 64-bit form and give the same records
+    as two launches of half the length (which take the 32-bit form)."""
+    m, n, k, nenv, steps = 9, 9, 5, 65536, 3000
+    a = hip.Rollout(hip.Env(m, n, k, nenv, device=DEV), seed=21)
+    whole = a.run(steps)
+    assert whole.planes.numel() * 8 > (1 << 32)
+    b = hip.Rollout(hip.Env(m, n, k, nenv, device=DEV), seed=21)
+    first = b.run(steps // 2)
+    assert torch.equal(first.planes, whole.planes[:steps // 2]) and torch.equal(first.meta, whole.meta[:steps // 2])
+    del first
+    second = b.run(steps - steps // 2)
+    assert torch.equal(second.planes, whole.planes[steps // 2:]) and torch.equal(second.meta, whole.meta[steps // 2:])
+    assert torch.equal(a.stats, b.stats) and torch.equal(a.env._planes, b.env._planes)
