@@ -19,6 +19,7 @@ struct MnkStage {
   uint32_t* words;    // [3*NW][B + 1]
   uint32_t* tab_obs;  // [2C]
   uint32_t* tab_mask; // [C]
+  uint32_t* segs;     // packed write-out: [2B + 1][SW] channel strings, then [B + 1][SW] legal strings
 };
 
 // row stride of the stage in words: B + 1, not B.  With B = 64 = the number of LDS banks, word w of env e sat in bank
@@ -27,8 +28,35 @@ struct MnkStage {
 // (w + e) mod 64: different words, different banks; lanes that want the same word are a broadcast.
 __host__ __device__ inline int mnk_stage_stride(int B) { return B + 1; }
 
-__host__ __device__ inline size_t mnk_stage_bytes(int NW, int C, int B) {
-  return (size_t)3 * NW * mnk_stage_stride(B) * 4 + (size_t)3 * C * 4;
+// ---- packed ("gap-free") strings, boards with a compile-time variant only -------------------------------------------
+// The staged words still carry the guard column; every float / mask byte of the output then costs a table lookup, a
+// word read and a wrap test (round 1: ~10 instructions and 2 LDS reads per cell; the bool mask, 1/8 of the bytes, took
+// half as long as the f32 observation).  For the boards with compile-time geometry the write-out therefore runs on
+// strings WITHOUT the guard bits: after the stage is filled, 3*B threads squeeze one string each (channel 0, channel 1,
+// legal cells of one env; row r of n bits moves from bit r*(n+1) to bit r*n, all shifts immediates) into
+//   segs  u32[2B + 1][SW]   segment 2*el + ch = channel ch of env el, C valid bits   (obs row of env el = its two segments)
+//   msegs u32[ B + 1][SW]   segment el = legal cells of env el
+// and 4 floats / 16 mask bytes of the output are then 4 / 16 CONSECUTIVE bits of a segment (continuing into the next
+// segment where one ends): two LDS words and a funnel shift, spread to bytes with one multiply
+// (nibble * 0x00204081 & 0x01010101) and, for the observation, to floats with v_cvt_f32_ubyte0..3.
+__host__ __device__ inline int mnk_seg_words(int NW, int n) {  // SW: words of one segment (odd, >= 1 zero pad word)
+  const int maxrows = 32 * NW / (n + 1);
+  const int cw = (maxrows * n + 31) / 32;
+  return (cw + 1) | 1;
+}
+
+// may this geometry take the packed write-out?  (the boards MNK_DISPATCH has compile-time variants for; 16 mask bytes
+// must not span more than two envs)
+__host__ __device__ inline bool mnk_geom_packed(int n, int k, int NW, int C) {
+  const bool fixed = (n == 9 && k == 5 && NW == 3) || (n == 13 && k == 5 && NW == 6) || (n == 15 && k == 5 && NW == 8) ||
+                     (n == 19 && k == 5 && NW == 12);
+  return fixed && C >= 16;
+}
+
+__host__ __device__ inline size_t mnk_stage_bytes(int NW, int C, int B, int n = 0, int k = 0) {
+  size_t bytes = (size_t)3 * NW * mnk_stage_stride(B) * 4 + (size_t)3 * C * 4;
+  if (mnk_geom_packed(n, k, NW, C)) bytes += (size_t)(3 * B + 2) * mnk_seg_words(NW, n) * 4;
+  return bytes;
 }
 
 __device__ __forceinline__ MnkStage mnk_stage_carve(void* lds, const MnkGeom& g, int B) {
@@ -36,10 +64,12 @@ __device__ __forceinline__ MnkStage mnk_stage_carve(void* lds, const MnkGeom& g,
   s.words = (uint32_t*)lds;
   s.tab_obs = s.words + (size_t)3 * g.NW * mnk_stage_stride(B);
   s.tab_mask = s.tab_obs + 2 * g.C;
+  s.segs = s.tab_obs + 3 * g.C;
   return s;
 }
 
 __device__ __forceinline__ void mnk_stage_tables(const MnkStage& s, const MnkGeom& g, int B, int tid, int nthreads) {
+  if (mnk_geom_packed(g.n, g.k, g.NW, g.C)) return;  // the packed write-out needs no cell tables
   for (int r = tid; r < 3 * g.C; r += nthreads) {
     const int plane = r >= 2 * g.C ? 2 : (r >= g.C ? 1 : 0);
     const uint32_t cell = (uint32_t)(r - plane * g.C);
@@ -133,4 +163,110 @@ __device__ __forceinline__ void mnk_emit_mask(const MnkStage& s, const MnkGeom& 
     const uint32_t el = mnk_div(e, g.magic_C);
     dst[e] = (uint8_t)mnk_stage_bit(st32, s.tab_mask[e - el * row], el);
   }
+}
+
+
+// ---------------------------------------------------------------- packed write-out (see mnk_seg_words above)
+// one thread = one string: squeeze the guard bits out of NW staged words into CW words (+ zero pad up to SW)
+template <int NW, int CN>
+__device__ __forceinline__ void mnk_stage_squeeze(const MnkStage& s, int B, int tid) {
+  constexpr int MAXROWS = 32 * NW / (CN + 1), CW = (MAXROWS * CN + 31) / 32, SW = (CW + 1) | 1;
+  if (tid >= 3 * B) return;
+  const int plane = tid / B, el = tid - plane * B, S = mnk_stage_stride(B);
+  uint32_t x[NW + 1];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) x[w] = s.words[(plane * NW + w) * S + el];
+  x[NW] = 0u;
+  uint32_t out[CW + 1];
+#pragma unroll
+  for (int w = 0; w <= CW; ++w) out[w] = 0u;
+#pragma unroll
+  for (int r = 0; r < MAXROWS; ++r) {
+    constexpr uint32_t rowmask = (1u << CN) - 1u;
+    const int sb = r * (CN + 1), q = sb >> 5, sh = sb & 31;
+    const uint32_t bits = ((sh + CN <= 32) ? (x[q] >> sh) : __builtin_amdgcn_alignbit(x[q + 1], x[q], (uint32_t)sh)) & rowmask;
+    const int db = r * CN, o = db >> 5, os = db & 31;
+    out[o] |= bits << os;
+    if (os + CN > 32) out[o + 1] |= bits >> (32 - os);
+  }
+  uint32_t* dst = s.segs + (size_t)(plane < 2 ? 2 * el + plane : 2 * B + 1 + el) * SW;
+#pragma unroll
+  for (int w = 0; w < SW; ++w) dst[w] = w < CW ? out[w] : 0u;
+}
+
+// 32 bits starting at bit `pos` of segment `sg` (C valid bits per segment), continuing with the first bits of
+// segment sg + 1 where the segment ends within the first K bits
+template <int K>
+__device__ __forceinline__ uint32_t mnk_seg_bits(const uint32_t* segs, int SW, uint32_t sg, uint32_t pos, uint32_t C) {
+  const uint32_t* p = segs + (size_t)sg * SW;
+  const uint32_t w = pos >> 5;
+  const uint32_t x = __builtin_amdgcn_alignbit(p[w + 1], p[w], pos & 31u);
+  const uint32_t left = C - pos;  // bits of this segment from `pos` on (>= 1)
+  const uint32_t next = p[SW];    // word 0 of the next segment (a zero pad segment follows the last one)
+  const uint32_t joined = (x & ((1u << (left & 31u)) - 1u)) | (next << (left & 31u));
+  return left < (uint32_t)K ? joined : x;
+}
+
+// 4 cells (low nibble) -> 4 bytes of 0 / 1
+__device__ __forceinline__ uint32_t mnk_spread4(uint32_t nib) { return ((nib & 0xFu) * 0x00204081u) & 0x01010101u; }
+
+template <int NW, int CN>
+__device__ __forceinline__ void mnk_emit_obs_packed(const MnkStage& s, const MnkGeom& g, int nb, float* dst, bool vec,
+                                                    int tid, int nthreads) {
+  constexpr int MAXROWS = 32 * NW / (CN + 1), CW = (MAXROWS * CN + 31) / 32, SW = (CW + 1) | 1;
+  const uint32_t C = (uint32_t)g.C, total = (uint32_t)nb * 2u * C;
+  const uint32_t nvec = vec ? (total >> 2) : 0u;
+  for (uint32_t q = tid; q < nvec; q += nthreads) {
+    const uint32_t e = q << 2, sg = mnk_div(e, g.magic_C), pos = e - sg * C;
+    const uint32_t b = mnk_spread4(mnk_seg_bits<4>(s.segs, SW, sg, pos, C));
+    reinterpret_cast<float4*>(dst)[q] = make_float4((float)(b & 0xFFu), (float)((b >> 8) & 0xFFu),
+                                                    (float)((b >> 16) & 0xFFu), (float)(b >> 24));
+  }
+  for (uint32_t e = (nvec << 2) + tid; e < total; e += nthreads) {
+    const uint32_t sg = mnk_div(e, g.magic_C), pos = e - sg * C;
+    dst[e] = (float)((s.segs[(size_t)sg * SW + (pos >> 5)] >> (pos & 31u)) & 1u);
+  }
+}
+
+template <int NW, int CN>
+__device__ __forceinline__ void mnk_emit_mask_packed(const MnkStage& s, const MnkGeom& g, int B, int nb, uint8_t* dst,
+                                                     bool vec, int tid, int nthreads) {
+  constexpr int MAXROWS = 32 * NW / (CN + 1), CW = (MAXROWS * CN + 31) / 32, SW = (CW + 1) | 1;
+  const uint32_t* msegs = s.segs + (size_t)(2 * B + 1) * SW;
+  const uint32_t C = (uint32_t)g.C, total = (uint32_t)nb * C;
+  const uint32_t nvec = vec ? (total >> 4) : 0u;
+  for (uint32_t q = tid; q < nvec; q += nthreads) {
+    const uint32_t e = q << 4, sg = mnk_div(e, g.magic_C), pos = e - sg * C;
+    const uint32_t x = mnk_seg_bits<16>(msegs, SW, sg, pos, C);
+    reinterpret_cast<uint4*>(dst)[q] = make_uint4(mnk_spread4(x), mnk_spread4(x >> 4), mnk_spread4(x >> 8), mnk_spread4(x >> 12));
+  }
+  for (uint32_t e = (nvec << 4) + tid; e < total; e += nthreads) {
+    const uint32_t sg = mnk_div(e, g.magic_C), pos = e - sg * C;
+    dst[e] = (uint8_t)((msegs[(size_t)sg * SW + (pos >> 5)] >> (pos & 31u)) & 1u);
+  }
+}
+
+// The write-out of a workgroup whose stage has been filled by mnk_stage_put: call from ALL threads of the workgroup
+// under a workgroup-uniform condition (it synchronises).  obs / mask may be NULL.
+template <int NW, int CN, int CK>
+__device__ __forceinline__ void mnk_write_out(const MnkStage& s, const MnkGeom& g, int B, int nb, float* obs, uint8_t* mask,
+                                              int vec_ok, int tid, int nthreads) {
+  __syncthreads();  // the stage is complete
+  if constexpr (CN != 0 && NW >= 3) {
+    if (mnk_geom_packed(CN, CK, NW, g.C)) {
+      // the pad segments that follow the last channel / legal segment: read (never used) by the last groups
+      constexpr int SW = ((((32 * NW / (CN + 1)) * CN + 31) / 32) + 1) | 1;
+      if (tid < SW) {
+        s.segs[(size_t)(2 * B) * SW + tid] = 0u;
+        s.segs[(size_t)(3 * B + 1) * SW + tid] = 0u;
+      }
+      for (int t = tid; t < 3 * B; t += nthreads) mnk_stage_squeeze<NW, CN>(s, B, t);
+      __syncthreads();
+      if (obs) mnk_emit_obs_packed<NW, CN>(s, g, nb, obs, vec_ok & 1, tid, nthreads);
+      if (mask) mnk_emit_mask_packed<NW, CN>(s, g, B, nb, mask, (vec_ok >> 1) & 1, tid, nthreads);
+      return;
+    }
+  }
+  if (obs) mnk_emit_obs(s, g, nb, obs, vec_ok & 1, tid, nthreads);
+  if (mask) mnk_emit_mask(s, g, nb, mask, (vec_ok >> 1) & 1, tid, nthreads);
 }

@@ -52,11 +52,10 @@ k_step_full(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_
     if (emit) mnk_stage_put<NW>(st, g, B, tid, e.p[0], e.p[1], false);
   }
   if (emit) {
-    __syncthreads();
     const int64_t left = N - env0;
     const int nb = left < B ? (int)left : B;
-    if (obs) mnk_emit_obs(st, g, nb, obs + env0 * 2 * g.C, vec_ok & 1, tid, NT);
-    if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, NT);
+    mnk_write_out<NW, CN, CK>(st, g, B, nb, obs ? obs + env0 * 2 * g.C : nullptr,
+                              legal_mask ? legal_mask + env0 * g.C : nullptr, vec_ok, tid, NT);
   }
 }
 
@@ -99,11 +98,10 @@ k_observe(MnkGeom g, const uint64_t* planes, int64_t N, const int64_t* flip_side
     if (flip) mnk_stage_put<NW>(st, g, B, tid, p1, p0, fix_empty != 0);
     else mnk_stage_put<NW>(st, g, B, tid, p0, p1, fix_empty != 0);
   }
-  __syncthreads();
   const int64_t left = N - env0;
   const int nb = left < B ? (int)left : B;
-  if (obs) mnk_emit_obs(st, g, nb, obs + env0 * 2 * g.C, vec_ok & 1, tid, NT);
-  if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, NT);
+  mnk_write_out<NW, CN, CK>(st, g, B, nb, obs ? obs + env0 * 2 * g.C : nullptr,
+                            legal_mask ? legal_mask + env0 * g.C : nullptr, vec_ok, tid, NT);
 }
 
 // dense f32 -> packed; rare path (the writable env.boards view), one lane per env
@@ -241,11 +239,10 @@ k_selfplay_pre(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int
     }
   }
   if (emit) {
-    __syncthreads();
     const int64_t left = N - env0;
     const int nb = left < B ? (int)left : B;
-    if (opp_obs) mnk_emit_obs(st, g, nb, opp_obs + env0 * 2 * g.C, vec_ok & 1, tid, NT);
-    if (opp_mask) mnk_emit_mask(st, g, nb, opp_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, NT);
+    mnk_write_out<NW, CN, CK>(st, g, B, nb, opp_obs ? opp_obs + env0 * 2 * g.C : nullptr,
+                              opp_mask ? opp_mask + env0 * g.C : nullptr, vec_ok, tid, NT);
   }
 }
 
@@ -291,12 +288,13 @@ k_selfplay_post(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const in
       else mnk_stage_put<NW>(st, g, B, tid, e.p[0], e.p[1], true);
     }
   }
-  if (emit || ep.stats) __syncthreads();
-  if (emit) {
+  if (emit) {  // (synchronises: the episode counters in LDS are complete after it, too)
     const int64_t left = N - env0;
     const int nb = left < B ? (int)left : B;
-    if (obs) mnk_emit_obs(st, g, nb, obs + env0 * 2 * g.C, vec_ok & 1, tid, NT);
-    if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, NT);
+    mnk_write_out<NW, CN, CK>(st, g, B, nb, obs ? obs + env0 * 2 * g.C : nullptr,
+                              legal_mask ? legal_mask + env0 * g.C : nullptr, vec_ok, tid, NT);
+  } else if (ep.stats) {
+    __syncthreads();
   }
   if (ep.stats) mnk_ep_flush(ep, lds_ep);
 }
@@ -349,12 +347,13 @@ k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, c
       else mnk_stage_put<NW>(st, g, B, tid, e.p[0], e.p[1], true);
     }
   }
-  if (emit || ep.stats) __syncthreads();
-  if (emit) {
+  if (emit) {  // (synchronises: the episode counters in LDS are complete after it, too)
     const int64_t left = N - env0;
     const int nb = left < B ? (int)left : B;
-    if (obs) mnk_emit_obs(st, g, nb, obs + env0 * 2 * g.C, vec_ok & 1, tid, NT);
-    if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + env0 * g.C, (vec_ok >> 1) & 1, tid, NT);
+    mnk_write_out<NW, CN, CK>(st, g, B, nb, obs ? obs + env0 * 2 * g.C : nullptr,
+                              legal_mask ? legal_mask + env0 * g.C : nullptr, vec_ok, tid, NT);
+  } else if (ep.stats) {
+    __syncthreads();
   }
   if (ep.stats) mnk_ep_flush(ep, lds_ep);
 }
@@ -385,12 +384,11 @@ k_unpack_records(MnkGeom g, const uint64_t* rec_planes, const uint32_t* rec_meta
     }
   }
   if (emit) {
-    __syncthreads();
     const int64_t left = N - env0;
     const int nb = left < B ? (int)left : B;
     const int64_t row0 = t * N + env0;
-    if (obs) mnk_emit_obs(st, g, nb, obs + row0 * 2 * g.C, vec_ok & 1, tid, NT);
-    if (masks) mnk_emit_mask(st, g, nb, masks + row0 * g.C, (vec_ok >> 1) & 1, tid, NT);
+    mnk_write_out<NW, CN, CK>(st, g, B, nb, obs ? obs + row0 * 2 * g.C : nullptr, masks ? masks + row0 * g.C : nullptr,
+                              vec_ok, tid, NT);
   }
 }
 
@@ -426,11 +424,10 @@ k_gather_obs(MnkGeom g, const uint64_t* planes, int64_t T, int64_t N, const int6
     }
     mnk_stage_put<NW>(st, g, B, tid, p0, p1, fix_empty != 0);
   }
-  __syncthreads();
   const int64_t left = B_total - row0;
   const int nb = left < B ? (int)left : B;
-  if (obs) mnk_emit_obs(st, g, nb, obs + row0 * 2 * g.C, vec_ok & 1, tid, NT);
-  if (legal_mask) mnk_emit_mask(st, g, nb, legal_mask + row0 * g.C, (vec_ok >> 1) & 1, tid, NT);
+  mnk_write_out<NW, CN, CK>(st, g, B, nb, obs ? obs + row0 * 2 * g.C : nullptr,
+                            legal_mask ? legal_mask + row0 * g.C : nullptr, vec_ok, tid, NT);
 }
 
 // ------------------------------------------------------------------ GAE (alg/rollout_buffer.py:60-80)
@@ -543,7 +540,7 @@ int mnk_observe(const uint64_t* planes, const uint32_t* meta, int64_t N, int m, 
   if (N == 0 || (!obs && !legal_mask)) return MNK_OK;
   const int B = mnk_block_envs(N);
   const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
-  const size_t lds = mnk_stage_bytes(g.NW, g.C, B);
+  const size_t lds = mnk_stage_bytes(g.NW, g.C, B, g.n, g.k);
   const dim3 grid((unsigned)((N + B - 1) / B));
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_observe), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, planes, N,
                                          flip_side, obs, legal_mask, fix_empty_mask, vec_ok, B));
@@ -582,7 +579,7 @@ int mnk_step(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, c
     const int B = mnk_block_envs(N);
     const bool emit = legal_mask || obs;
     const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
-    const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B) : 0;
+    const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, g.k) : 0;
     const dim3 grid((unsigned)((N + B - 1) / B));
     MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_step_full), grid, dim3(mnk_block_threads()), lds, s, g, planes, meta, N, actions,
                                            rewards, dones, legal_mask, obs, err, flags, vec_ok, B));
@@ -630,7 +627,7 @@ int mnk_selfplay_pre(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, 
   const int B = mnk_block_envs(N);
   const bool emit = opp_obs || opp_mask;
   const int vec_ok = (aligned16(opp_obs) ? 1 : 0) | (aligned16(opp_mask) ? 2 : 0);
-  const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B) : 0;
+  const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, g.k) : 0;
   const dim3 grid((unsigned)((N + B - 1) / B));
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_pre), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, planes, meta,
                                          N, actions, pending, agent_side, forced_side, seed, step, step_dev, env_id0,
@@ -653,7 +650,7 @@ int mnk_selfplay_post(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n,
   const int B = mnk_block_envs(N);
   const bool emit = obs || legal_mask;
   const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
-  const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B) : 0;
+  const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, g.k) : 0;
   const dim3 grid((unsigned)((N + B - 1) / B));
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_post), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, planes,
                                          meta, N, opp_actions, sp_flags, agent_side, rewards, terminated, pending, obs,
@@ -676,7 +673,7 @@ int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m,
   const int B = mnk_block_envs(N);
   const bool emit = obs || legal_mask;
   const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
-  const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B) : 0;
+  const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, g.k) : 0;
   const dim3 grid((unsigned)((N + B - 1) / B));
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_step_random), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g,
                                          planes, meta, N, actions, pending, agent_side, forced_side, seed, step,
@@ -697,7 +694,7 @@ int mnk_unpack_records(const uint64_t* rec_planes, const uint32_t* rec_meta, int
   const bool obs_vec = aligned16(obs) && ((N * 2 * g.C * 4) % 16 == 0);
   const bool mask_vec = aligned16(masks) && ((N * g.C) % 16 == 0);
   const int vec_ok = (obs_vec ? 1 : 0) | (mask_vec ? 2 : 0);
-  const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B) : 0;
+  const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, g.k) : 0;
   const dim3 grid((unsigned)((N + B - 1) / B), (unsigned)T);
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_unpack_records), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, rec_planes,
                                          rec_meta, N, obs, masks, actions, rewards, dones, vec_ok, B));
@@ -713,7 +710,7 @@ int mnk_gather_obs(const uint64_t* planes, int64_t T, int64_t N, int m, int n, c
   if (B == 0 || (!obs && !legal_mask)) return MNK_OK;
   const int E = mnk_block_envs(B);
   const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
-  const size_t lds = mnk_stage_bytes(g.NW, g.C, E);
+  const size_t lds = mnk_stage_bytes(g.NW, g.C, E, g.n, g.k);
   const dim3 grid((unsigned)((B + E - 1) / E));
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_gather_obs), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g,
                                      planes, T, N, idx, B, obs, legal_mask, fix_empty_mask, err, vec_ok, E));
