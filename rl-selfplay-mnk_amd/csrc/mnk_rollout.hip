@@ -8,25 +8,40 @@
 // The receiving side of the multi-GPU exchange: a shard's rollout is fully determined by its
 // chunk-start state and its action log (1-2 bytes per ply), so that is what crosses xGMI; this
 // kernel re-plays the log and rebuilds the full packed records, bit-identical to the sender's.
-template <int NW, int CN, int CK, bool RECORD>
+// ACTB = bytes per logged action (1 or 2), a template parameter like everything else that shapes the ply loop: four
+// plies per log word, unrolled with compile-time field positions (round 1 looped ply by ply with a run-time field
+// and a branch per ply: 1.2e11 env-steps/s, slower than producing the log); the next word is fetched while the
+// current four plies are played.
+template <int NW, int CN, int CK, bool RECORD, int ACTB>
 __global__ void __launch_bounds__(64)
-k_replay_actions(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, const void* act_log, int act_bytes,
+k_replay_actions(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, const void* act_log,
                  uint64_t* rec_planes, uint32_t* rec_meta, int32_t* err) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   RolloutLane<NW, CN, CK, RECORD> L(g, N, i, rec_planes, rec_meta, nullptr);
   L.load(planes, meta, i);
-  const uint32_t* q32 = (const uint32_t*)act_log;
-  const uint64_t* q64 = (const uint64_t*)act_log;
+  constexpr uint32_t FIELD = ACTB == 1 ? 0xFFu : 0xFFFFu;
+  auto fetch = [&](int q) -> uint64_t {
+    if (ACTB == 1) return (uint64_t)((const uint32_t*)act_log)[(int64_t)q * N + i];
+    return ((const uint64_t*)act_log)[(int64_t)q * N + i];
+  };
   bool bad = false;
-  uint64_t quad = 0;
-  for (int t = 0; t < T; ++t) {
-    if ((t & 3) == 0) quad = act_bytes == 1 ? (uint64_t)q32[(int64_t)(t >> 2) * N + i] : q64[(int64_t)(t >> 2) * N + i];
-    int a = act_bytes == 1 ? (int)(quad & 0xFFu) : (int)(quad & 0xFFFFu);
-    quad >>= 8 * act_bytes;
-    if (a >= g.C) { bad = true; a = 0; }  // a log we did not write: flag it, keep the wave in step
-    L.ply_action(a);
+  auto play = [&](uint32_t a) {
+    if (a >= (uint32_t)g.C) { bad = true; a = 0; }  // a log we did not write: flag it, keep the wave in step
+    L.ply_action((int)a);
+  };
+  const int words = (T + 3) >> 2;
+  uint64_t ahead = words ? fetch(0) : 0;
+  int t = 0;
+  for (int q = 0; t + 4 <= T; ++q, t += 4) {
+    const uint64_t quad = ahead;
+    ahead = fetch(q + 1 < words ? q + 1 : q);
+    play((uint32_t)(quad >> (0 * 8 * ACTB)) & FIELD);
+    play((uint32_t)(quad >> (1 * 8 * ACTB)) & FIELD);
+    play((uint32_t)(quad >> (2 * 8 * ACTB)) & FIELD);
+    play((uint32_t)(quad >> (3 * 8 * ACTB)) & FIELD);
   }
+  for (uint64_t quad = ahead; t < T; ++t, quad >>= 8 * ACTB) play((uint32_t)quad & FIELD);  // a partly filled last word
   if (bad) mnk_report(err, MNK_ERR_ACTION_RANGE, i);
   L.store(planes, meta, i);
 }
@@ -138,14 +153,16 @@ int mnk_replay_actions(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   if (N == 0 || T == 0) return MNK_OK;
   const int B = 64;
   const dim3 grid((unsigned)((N + B - 1) / B));
-  if (rec_planes && rec_meta)
-    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_replay_actions<NW, CN, CK, true>), grid, dim3(B), 0,
-                                       (hipStream_t)stream, g, planes, meta, N, T, act_log, act_bytes, rec_planes,
-                                       rec_meta, err));
-  else
-    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_replay_actions<NW, CN, CK, false>), grid, dim3(B), 0,
-                                       (hipStream_t)stream, g, planes, meta, N, T, act_log, act_bytes, nullptr,
-                                       nullptr, err));
+#define MNK_REPLAY(REC, ACTB)                                                                                       \
+  MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_replay_actions<NW, CN, CK, REC, ACTB>), grid, dim3(B), 0,    \
+                                     (hipStream_t)stream, g, planes, meta, N, T, act_log, REC ? rec_planes : nullptr, \
+                                     REC ? rec_meta : nullptr, err))
+  const bool rec = rec_planes && rec_meta;
+  if (rec && act_bytes == 1) MNK_REPLAY(true, 1);
+  else if (rec) MNK_REPLAY(true, 2);
+  else if (act_bytes == 1) MNK_REPLAY(false, 1);
+  else MNK_REPLAY(false, 2);
+#undef MNK_REPLAY
   return mnk_launch_status("replay_actions");
 }
 
