@@ -241,10 +241,13 @@ def replay_rate(env, roll, chunk, reps=8):
     logs.msg.copy_(rec.msg.unsqueeze(0))
     out = replay_shard(logs, 0, env.m, env.n, env.k)
     assert torch.equal(out.planes, rec.planes) and torch.equal(out.meta, rec.meta), "replay != records"
+    scratch = (torch.empty_like(env._planes), torch.empty_like(env._meta))
+    err = torch.zeros(2, dtype=torch.int32, device=env._dev)
+    replay_shard(logs, 0, env.m, env.n, env.k, err=err, out=out, scratch=scratch)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
-        replay_shard(logs, 0, env.m, env.n, env.k, out=out)
+        replay_shard(logs, 0, env.m, env.n, env.k, err=err, out=out, scratch=scratch)
     torch.cuda.synchronize()
     return reps * chunk * env.num_envs / (time.perf_counter() - t0)
 

@@ -201,15 +201,22 @@ def gather_action_logs(rec: RolloutRecords, group=None, out: Optional[GatheredLo
 
 
 def replay_shard(logs: GatheredLogs, shard: int, m: int, n: int, k: int, err: Optional[torch.Tensor] = None,
-                 out: Optional[RolloutRecords] = None) -> RolloutRecords:
+                 out: Optional[RolloutRecords] = None, scratch=None) -> RolloutRecords:
     """Rebuilds shard ``shard``'s full packed records from its gathered state + action log
-    (``mnk_replay_actions``, one launch); bit-identical to what the owning rank recorded."""
+    (``mnk_replay_actions``, one launch); bit-identical to what the owning rank recorded.
+    ``scratch``: optional ``(planes int64 [2, W, N], meta int32 [N])`` buffers for the state the replay advances
+    (reused across calls instead of two fresh copies)."""
     act = logs.act[shard]
     t, nenv = logs.steps, act.shape[1]
     assert act.shape[0] == (t + 3) // 4, "GatheredLogs.steps does not match the packed log"
     dev = act.device
-    planes = logs.planes0[shard].clone()
-    meta = logs.meta0[shard].clone()
+    if scratch is not None:
+        planes, meta = scratch
+        planes.copy_(logs.planes0[shard])
+        meta.copy_(logs.meta0[shard])
+    else:
+        planes = logs.planes0[shard].clone()
+        meta = logs.meta0[shard].clone()
     if out is None:
         out = RolloutRecords(planes=torch.empty((t, mnk_hip.record_words(m, n), nenv), dtype=torch.int64, device=dev),
                              meta=torch.empty((t, nenv), dtype=torch.int32, device=dev))
