@@ -271,7 +271,7 @@ void dispatch_sample(const void* logits, const uint8_t* mask, int64_t N, int C, 
                      hipStream_t s) {
 #define MNK_SAMPLE(LPRv, Kv, EXv) \
   launch_sample<LPRv, Kv, EXv, LT>(logits, mask, N, C, seed, step, step_dev, env_id0, deterministic, actions, logp, s)
-  // lanes per row x cells per lane (tools/exp_sample.py: 4 lanes per row beat 8 at 9x9, ...)
+  // lanes per row x cells per lane, by measurement (9x9: 4 lanes per row 7.1 us, 8 lanes per row 9.9 us; profiles/r02_api_kernels.md)
   if (C == 81) MNK_SAMPLE(4, 21, true);          // 9x9
   else if (C == 9) MNK_SAMPLE(4, 3, true);       // 3x3
   else if (C == 169) MNK_SAMPLE(8, 22, true);    // 13x13
