@@ -341,6 +341,22 @@ class TorchVectorMnkEnv:
             mnk_hip.call("mnk_reset_mask", mnk_hip.ptr(self._planes), mnk_hip.ptr(self._meta), self.num_envs,
                          self.words, mnk_hip.ptr(mask_u8), self._stream())
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """The whole env state (packed planes + meta words, 36 B per env at 9x9) as CPU tensors; with the Philox
+        step counters of the wrapper / rollout driver a run resumes bit-exactly."""
+        self.check_errors()
+        return {"geometry": torch.tensor([self.m, self.n, self.k, self.num_envs]),
+                "planes": self._planes.cpu(), "meta": self._meta.cpu()}
+
+    def load_state_dict(self, state: Dict[str, torch.Tensor]) -> None:
+        if state["geometry"].tolist() != [self.m, self.n, self.k, self.num_envs]:
+            raise ValueError(f"state is for {state['geometry'].tolist()}, this env is "
+                             f"{[self.m, self.n, self.k, self.num_envs]}")
+        self._planes.copy_(state["planes"])
+        self._meta.copy_(state["meta"])
+        self._err.zero_()
+
     # ------------------------------------------------------------------ helpers
     def _flags(self) -> int:
         return mnk_hip.STEP_STRICT if self.strict else 0

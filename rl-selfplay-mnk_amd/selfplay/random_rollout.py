@@ -77,6 +77,16 @@ class RandomRollout:
         """int64[5]: episodes finished, black wins, white wins, draws, sum of finished-episode lengths"""
         return self._stats.sum(dim=0)[:mnk_hip.STATS_COUNTERS]
 
+    def state_dict(self) -> dict:
+        """env state + Philox key, step counter and statistics: a driver restored from it continues bit-exactly"""
+        return {"env": self.env.state_dict(), "seed": self.seed, "env_id0": self.env_id0, "step": self.step,
+                "stats": self._stats.cpu()}
+
+    def load_state_dict(self, state: dict) -> None:
+        self.env.load_state_dict(state["env"])
+        self.seed, self.env_id0, self.step = int(state["seed"]), int(state["env_id0"]), int(state["step"])
+        self._stats.copy_(state["stats"])
+
     def alloc(self, steps: int, log_actions: bool = False) -> RolloutRecords:
         env = self.env
         rec = RolloutRecords(

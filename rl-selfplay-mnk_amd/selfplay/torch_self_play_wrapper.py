@@ -100,6 +100,26 @@ class TorchSelfPlayWrapper:
                 "mean_reward": (wins - losses) / episodes if episodes else 0.0,
                 "mean_length": length / episodes if episodes else 0.0}
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self) -> dict:
+        """Env state + sides, pending resets, Philox key and step counter (+ episode accounting when tracked): a
+        wrapper restored from it continues exactly where this one stands."""
+        out = {"env": self.env.state_dict(), "agent_side": self.agent_side.cpu(), "pending_resets": self.pending_resets.cpu(),
+               "seed": self.seed, "step_count": self.step_count, "env_id0": self.env_id0}
+        if self._ep_stats is not None:
+            out["episodes"] = (self._ep_return.cpu(), self._ep_length.cpu(), self._ep_stats.cpu())
+        return out
+
+    def load_state_dict(self, state: dict) -> None:
+        self.env.load_state_dict(state["env"])
+        self.agent_side.copy_(state["agent_side"])
+        self.pending_resets.copy_(state["pending_resets"])
+        self.seed, self.step_count, self.env_id0 = int(state["seed"]), int(state["step_count"]), int(state["env_id0"])
+        if "episodes" in state:
+            self.track_episodes()
+            for dst, src in zip((self._ep_return, self._ep_length, self._ep_stats), state["episodes"]):
+                dst.copy_(src)
+
     # ------------------------------------------------------------------ reference surface
     def reset(self, seed=None, options=None):
         """reference wrapper:19-30 (``seed`` is accepted and ignored there; here it re-keys Philox)"""

@@ -824,3 +824,44 @@ def test_sampler_all_row_widths(hip, m, n):
     first = sampler.draw(None, mask, True)
     want = torch.argmax(legal.to(torch.uint8), dim=1)
     assert torch.equal(first, want)
+
+
+def test_checkpoint_resume_is_bit_exact(hip, tmp_path):
+    """state_dict / load_state_dict of the env, the wrapper (with episode accounting) and the rollout driver:
+    a run restored from a checkpoint written to disk continues exactly like the run that wrote it."""
+    m, n, k, nenv = 9, 9, 5, 300
+    # wrapper + fused random opponent
+    w1 = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV), seed=4)
+    w1.set_opponent(hip.policy.RandomPolicy(m * n, seed=8))
+    w1.track_episodes()
+    agent = hip.policy.RandomPolicy(m * n, seed=9)
+    obs, _ = w1.reset()
+    for _ in range(40):
+        obs, *_ = w1.step(agent.act(obs))
+    torch.save({"wrapper": w1.state_dict(), "agent_calls": agent._sampler.calls}, tmp_path / "ckpt.pt")
+    tail1 = []
+    for _ in range(30):
+        obs, r, t, _, _ = w1.step(agent.act(obs))
+        tail1.append((obs["observation"].clone(), r.clone(), t.clone()))
+    ck = torch.load(tmp_path / "ckpt.pt", weights_only=False)  # our own file
+    w2 = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV), seed=123)
+    w2.set_opponent(hip.policy.RandomPolicy(m * n, seed=8))
+    w2.load_state_dict(ck["wrapper"])
+    agent2 = hip.policy.RandomPolicy(m * n, seed=9)
+    agent2._sampler.calls = ck["agent_calls"]
+    obs2 = w2.get_agent_obs()
+    for (o, r, t) in tail1:
+        obs2, r2, t2, _, _ = w2.step(agent2.act(obs2))
+        assert torch.equal(obs2["observation"], o) and torch.equal(r2, r) and torch.equal(t2, t)
+    assert w1.pop_episode_stats() == w2.pop_episode_stats()
+    # rollout driver
+    a = hip.rollout.RandomRollout(hip.Env(m, n, k, nenv, device=DEV), seed=5)
+    a.run(64, record=False)
+    state = a.state_dict()
+    want = a.run(32)
+    b = hip.rollout.RandomRollout(hip.Env(m, n, k, nenv, device=DEV), seed=0)
+    b.load_state_dict(state)
+    got = b.run(32)
+    assert torch.equal(got.planes, want.planes) and torch.equal(got.meta, want.meta) and torch.equal(a.stats, b.stats)
+    with pytest.raises(ValueError, match="state is for"):
+        hip.Env(3, 3, 3, nenv, device=DEV).load_state_dict(state["env"])
