@@ -219,8 +219,9 @@ __device__ __forceinline__ void mnk_emit_obs_packed(const MnkStage& s, const Mnk
   for (uint32_t q = tid; q < nvec; q += nthreads) {
     const uint32_t e = q << 2, sg = mnk_div(e, g.magic_C), pos = e - sg * C;
     const uint32_t b = mnk_spread4(mnk_seg_bits<4>(s.segs, SW, sg, pos, C));
-    reinterpret_cast<float4*>(dst)[q] = make_float4((float)(b & 0xFFu), (float)((b >> 8) & 0xFFu),
-                                                    (float)((b >> 16) & 0xFFu), (float)(b >> 24));
+    // (wave-uniform slab base + 32-bit lane offset: global_store ... s[base])
+    *reinterpret_cast<float4*>((char*)dst + (uint64_t)(q << 4)) =
+        make_float4((float)(b & 0xFFu), (float)((b >> 8) & 0xFFu), (float)((b >> 16) & 0xFFu), (float)(b >> 24));
   }
   for (uint32_t e = (nvec << 2) + tid; e < total; e += nthreads) {
     const uint32_t sg = mnk_div(e, g.magic_C), pos = e - sg * C;
@@ -238,7 +239,8 @@ __device__ __forceinline__ void mnk_emit_mask_packed(const MnkStage& s, const Mn
   for (uint32_t q = tid; q < nvec; q += nthreads) {
     const uint32_t e = q << 4, sg = mnk_div(e, g.magic_C), pos = e - sg * C;
     const uint32_t x = mnk_seg_bits<16>(msegs, SW, sg, pos, C);
-    reinterpret_cast<uint4*>(dst)[q] = make_uint4(mnk_spread4(x), mnk_spread4(x >> 4), mnk_spread4(x >> 8), mnk_spread4(x >> 12));
+    *reinterpret_cast<uint4*>((char*)dst + (uint64_t)(q << 4)) =
+        make_uint4(mnk_spread4(x), mnk_spread4(x >> 4), mnk_spread4(x >> 8), mnk_spread4(x >> 12));
   }
   for (uint32_t e = (nvec << 4) + tid; e < total; e += nthreads) {
     const uint32_t sg = mnk_div(e, g.magic_C), pos = e - sg * C;
