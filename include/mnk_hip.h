@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define MNK_ABI_VERSION 3
+#define MNK_ABI_VERSION 4
 
 /* status codes (host-side argument checks) */
 #define MNK_OK 0
@@ -68,6 +68,15 @@ extern "C" {
 #define MNK_STEP_AUTORESET 2u /* mnk_step, full batch only: an env whose game this ply finished is reset in the same launch
                                * (env.reset(nonzero(done)), env/torch_vector_mnk_env.py:34-44) and the legal mask / observation
                                * written are those of the fresh board -- the raw loop "step; reset(done); observe" in one launch */
+
+/* element type of the observations a kernel writes (`obs_dtype` next to every `obs` pointer).  A cell is exactly
+ * 0 or 1, so every narrowing is lossless: obs.float() of a narrow observation equals the f32 one bit for bit.
+ * F32 is what the reference hands out (env/torch_vector_mnk_env.py:17, :52); BF16 is what its first convolution
+ * computes in under alg/ppo.py:194 autocast (utils/hardware.py:38-41) -- the cast the caller does today is a separate
+ * elementwise kernel over 648 B/env; U8 is 0/1 bytes.  Halves / quarters the dominant bytes of every API kernel. */
+#define MNK_OBS_F32 0
+#define MNK_OBS_BF16 1
+#define MNK_OBS_U8 2
 
 /* element type of the logits handed to mnk_sample_logits */
 #define MNK_LOGITS_F32 0
@@ -124,8 +133,19 @@ int mnk_reset_mask(uint64_t* planes, uint32_t* meta, int64_t N, int W, const uin
  * (NULL = skip) and always cover all N envs. */
 int mnk_step(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k,
              const int64_t* actions, const int64_t* active_idx, int64_t A,
-             float* rewards, uint8_t* dones, uint8_t* legal_mask, float* obs,
+             float* rewards, uint8_t* dones, uint8_t* legal_mask, void* obs, int obs_dtype,
              int32_t* err, uint32_t flags, void* stream);
+
+/* ---- BASELINE.json config 2 in ONE launch per ply: RandomPolicy.act (selfplay/policy.py:18-29) -> env.step
+ * (env/torch_vector_mnk_env.py:55-84, win scan :106-119) -> env.reset(nonzero(done)) (:34-44) -> observe (:46-53).
+ * Every env draws its own uniformly random legal move -- Philox(seed, env_id0 + i, step [+ *step_dev], stream_id),
+ * the draw of mnk_sample_legal -- plays it, and (flags & MNK_STEP_AUTORESET) restarts if the game ended; rewards /
+ * dones / legal_mask / obs as in mnk_step; actions_out (optional) int64[N] receives the moves played.
+ * T such launches with step = s .. s+T-1 and MNK_STEP_AUTORESET play the plies of mnk_rollout_random(T, step0 = s). */
+int mnk_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k,
+                    uint64_t seed, uint64_t step, const uint64_t* step_dev, int64_t env_id0, int stream_id,
+                    int64_t* actions_out, float* rewards, uint8_t* dones, uint8_t* legal_mask, void* obs, int obs_dtype,
+                    uint32_t flags, void* stream);
 
 /* ---- env/torch_vector_mnk_env.py:46-53 observe() and
  *      selfplay/torch_self_play_wrapper.py:99-112 _get_canonical_obs() --------------------
@@ -133,8 +153,11 @@ int mnk_step(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k,
  * planes swapped (the agent sees itself in channel 0).  fix_empty_mask != 0 sets
  * mask[i][0] = 1 for rows without a legal cell (wrapper:108-110). obs or mask may be NULL. */
 int mnk_observe(const uint64_t* planes, const uint32_t* meta, int64_t N, int m, int n,
-                const int64_t* flip_side, float* obs, uint8_t* legal_mask, int fix_empty_mask,
-                void* stream);
+                const int64_t* flip_side, void* obs, int obs_dtype, uint8_t* legal_mask, int fix_empty_mask,
+                uint64_t* packed_obs, void* stream);
+/* packed_obs (optional, here and in mnk_selfplay_post / mnk_selfplay_step_random): the same view as `obs` as packed
+ * planes u64[2][W][N], channel 0 = the viewer's stones -- 16*W B per env (32 B at 9x9) instead of the 8C + C B of
+ * observation + mask; what alg.packed_rollout_buffer.PackedRolloutBuffer stores and mnk_gather_obs expands. */
 
 /* dense (N,2,m,n) f32 <-> packed planes: backs the writable `env.boards` view
  * (tests/test_mnk_integration.py:57-58 pokes stones in).  A cell is a stone when != 0. */
@@ -177,12 +200,16 @@ int mnk_selfplay_pre(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, 
                      const int64_t* actions, const uint8_t* pending, int64_t* agent_side,
                      const int64_t* forced_side, uint64_t seed, uint64_t step, const uint64_t* step_dev,
                      int64_t env_id0, float* rewards, uint8_t* terminated, uint8_t* sp_flags,
-                     float* opp_obs, uint8_t* opp_mask, int32_t* err, uint32_t flags, void* stream);
+                     void* opp_obs, int obs_dtype, uint8_t* opp_mask, int32_t* err, uint32_t flags, void* stream);
 int mnk_selfplay_post(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k,
                       const int64_t* opp_actions, const uint8_t* sp_flags, const int64_t* agent_side,
                       float* rewards, uint8_t* terminated, uint8_t* pending,
-                      float* obs, uint8_t* legal_mask, int32_t* err,
+                      void* obs, int obs_dtype, uint8_t* legal_mask, uint64_t* packed_obs, int32_t* err,
                       float* ep_return, int32_t* ep_length, int64_t* ep_stats, uint32_t flags, void* stream);
+/* Every output is caller-owned and may point INTO the rollout sink: obs / legal_mask at row t+1 of the
+ * RolloutBuffer's observations / action_masks (alg/rollout_buffer.py:14-44), rewards / terminated at row t of its
+ * rewards / dones -- the step then writes each agent-step once, where the reference writes it, reads it back and
+ * writes it again in RolloutBuffer.add (alg/rollout_buffer.py:47-58: 7 copy_ per step). */
 /* flags: MNK_STEP_STRICT makes an agent / opponent move onto an occupied cell an MNK_ERR_ILLEGAL_MOVE (the env is
  * left untouched) instead of the reference's silent overwrite (env/torch_vector_mnk_env.py:67-69).
  * ep_* (all three or none; NULL = off): device-side episode accounting replacing the host loop of
@@ -195,7 +222,8 @@ int mnk_selfplay_post(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n,
 int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k,
                              const int64_t* actions, uint8_t* pending, int64_t* agent_side,
                              const int64_t* forced_side, uint64_t seed, uint64_t step, const uint64_t* step_dev,
-                             int64_t env_id0, float* rewards, uint8_t* terminated, float* obs, uint8_t* legal_mask,
+                             int64_t env_id0, float* rewards, uint8_t* terminated, void* obs, int obs_dtype,
+                             uint8_t* legal_mask, uint64_t* packed_obs,
                              int32_t* err, float* ep_return, int32_t* ep_length, int64_t* ep_stats,
                              uint32_t flags, void* stream);
 
@@ -239,7 +267,7 @@ int mnk_replay_actions(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
  * obs f32[T][N][2][m][n] from the mover's point of view, masks u8[T][N][C], actions i64[T][N],
  * rewards f32[T][N], dones u8[T][N].  Any output may be NULL. */
 int mnk_unpack_records(const uint64_t* rec_planes, const uint32_t* rec_meta, int64_t N, int T, int m, int n,
-                       float* obs, uint8_t* masks, int64_t* actions, float* rewards, uint8_t* dones,
+                       void* obs, int obs_dtype, uint8_t* masks, int64_t* actions, float* rewards, uint8_t* dones,
                        void* stream);
 
 /* ---- alg/rollout_buffer.py:82-113 get_data_loader: a shuffled minibatch straight from PACKED observations.
@@ -247,7 +275,7 @@ int mnk_unpack_records(const uint64_t* rec_planes, const uint32_t* rec_meta, int
  * sample ids t*N + i (negative ids wrap, out-of-range -> err).  Writes the network inputs of the B samples:
  * obs f32[B][2][m][n] and legal mask u8[B][m*n] (free cells; fix_empty_mask as in wrapper:108-110). */
 int mnk_gather_obs(const uint64_t* planes, int64_t T, int64_t N, int m, int n, const int64_t* idx, int64_t B,
-                   float* obs, uint8_t* legal_mask, int fix_empty_mask, int32_t* err, void* stream);
+                   void* obs, int obs_dtype, uint8_t* legal_mask, int fix_empty_mask, int32_t* err, void* stream);
 
 /* ---- alg/rollout_buffer.py:60-80 compute_advantages_and_returns (GAE), one lane per env ---- */
 int mnk_gae(const float* rewards, const float* values, const uint8_t* dones, const float* last_values,

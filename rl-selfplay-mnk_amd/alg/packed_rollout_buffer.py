@@ -11,7 +11,9 @@ the dense drop-in buffer.
 The caller adds ``wrapper.packed_obs()`` -- taken when the observation was handed out, i.e. before the
 ``wrapper.step`` that consumes the action -- instead of the dense observation and mask; everything else
 (``add`` order, ``ptr``, "Buffer was full.", ``compute_advantages_and_returns``, ``reset``) is the
-reference's.
+reference's.  With ``wrapper.attach_sink(buffer)`` the step kernel itself writes the packed canonical planes into
+row t+1 (and rewards / terminated into row t): ``add(buffer.row(t)["packed"], ...)`` then copies nothing, and the
+dense observation the network needs for the next forward is the only other thing the step writes.
 """
 import torch
 
@@ -28,11 +30,19 @@ class PackedRolloutBuffer:
         self.words = mnk_hip.state_words(m, n)
         self.device = device
         self._err = torch.zeros(2, dtype=torch.int32, device=device)
+        self.copied_bytes = 0  # bytes ``add`` really copied so far
         self.reset()
 
     def reset(self):
         t, n, dev = self.n_steps, self.num_envs, self.device
-        self.planes = torch.zeros((t, 2, self.words, n), dtype=torch.int64, device=dev)
+        if getattr(self, "planes", None) is not None:  # keep the storage: rows may be bound to the fused step
+            for f in (self._plane_store, self.actions, self.log_probs, self.rewards, self.values, self.returns,
+                      self.advantages, self.dones):
+                f.zero_()
+            self.ptr = 0
+            return
+        self._plane_store = torch.zeros((t + 1, 2, self.words, n), dtype=torch.int64, device=dev)  # + the spill row
+        self.planes = self._plane_store[:t]
         self.actions = torch.zeros((t, n), dtype=torch.long, device=dev)
         self.log_probs = torch.zeros((t, n), dtype=torch.float32, device=dev)
         self.rewards = torch.zeros((t, n), dtype=torch.float32, device=dev)
@@ -42,16 +52,34 @@ class PackedRolloutBuffer:
         self.dones = torch.zeros((t, n), dtype=torch.bool, device=dev)
         self.ptr = 0
 
+    # ------------------------------------------------------------------ the sink of the fused step
+    def row(self, t: int) -> dict:
+        if not 0 <= t <= self.n_steps:
+            raise IndexError(f"row {t} of a buffer of {self.n_steps} steps")
+        out = {"packed": self._plane_store[t]}
+        if t < self.n_steps:
+            out.update(actions=self.actions[t], log_probs=self.log_probs[t], rewards=self.rewards[t],
+                       values=self.values[t], dones=self.dones[t], terminated=self.dones[t])
+        return out
+
+    def reset_outputs(self):
+        return {"packed": self._plane_store[self.ptr]} if self.ptr < self.n_steps else None
+
+    def step_outputs(self):
+        t = self.ptr
+        if t >= self.n_steps:
+            return None
+        return {"packed": self._plane_store[t + 1], "rewards": self.rewards[t], "terminated": self.dones[t]}
+
     def add(self, packed_obs, action, reward, value, log_prob, done):
         if self.ptr >= self.n_steps:
             raise IndexError("Buffer was full.")
+        from alg.rollout_buffer import _put
+
         row = self.ptr
-        self.planes[row].copy_(packed_obs)
-        self.actions[row].copy_(action)
-        self.rewards[row].copy_(reward)
-        self.values[row].copy_(value.view(-1))
-        self.log_probs[row].copy_(log_prob)
-        self.dones[row].copy_(done)
+        self.copied_bytes += (_put(self.planes[row], packed_obs) + _put(self.actions[row], action) +
+                              _put(self.rewards[row], reward) + _put(self.values[row], value.view(-1)) +
+                              _put(self.log_probs[row], log_prob) + _put(self.dones[row], done))
         self.ptr += 1
 
     def compute_advantages_and_returns(self, last_values, gamma=0.99, gae_lambda=0.95):
@@ -64,17 +92,17 @@ class PackedRolloutBuffer:
                      mnk_hip.ptr(self.advantages), mnk_hip.ptr(self.returns),
                      mnk_hip.stream_ptr(self.rewards.device))
 
-    def gather(self, flat_idx):
-        """(obs f32 [B,2,m,n], mask bool [B,C]) of the samples ``flat_idx`` (= t*N + i), one launch."""
+    def gather(self, flat_idx, obs_dtype=torch.float32):
+        """(obs [B,2,m,n] float32 / bfloat16 / uint8, mask bool [B,C]) of the samples ``flat_idx`` (= t*N + i), one launch."""
         idx = flat_idx.to(torch.long).contiguous()
         b = idx.numel()
         dev = self.planes.device
-        obs = torch.empty((b, 2, self.m, self.n), dtype=torch.float32, device=dev)
+        obs = torch.empty((b, 2, self.m, self.n), dtype=obs_dtype, device=dev)
         mask = torch.empty((b, self.action_dim), dtype=torch.bool, device=dev)
         if b:
             mnk_hip.call("mnk_gather_obs", mnk_hip.ptr(self.planes), self.n_steps, self.num_envs, self.m, self.n,
-                         mnk_hip.ptr(idx), b, mnk_hip.ptr(obs), mnk_hip.ptr(mask), 1, mnk_hip.ptr(self._err),
-                         mnk_hip.stream_ptr(dev))
+                         mnk_hip.ptr(idx), b, mnk_hip.ptr(obs), mnk_hip.obs_code(obs), mnk_hip.ptr(mask), 1,
+                         mnk_hip.ptr(self._err), mnk_hip.stream_ptr(dev))
         return obs, mask
 
     def get_data_loader(self, batch_size, normalize_advantages=True):

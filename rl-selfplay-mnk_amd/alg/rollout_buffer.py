@@ -7,6 +7,12 @@ Same constructor, fields (``[T, N, ...]`` device tensors, same names and dtypes)
 steps x ~8 eager launches -- is one launch of ``mnk_gae`` (one lane per env, reverse scan over T, coalesced
 over the env axis) with the reference's operation order and f32 roundings, so the results are bit-identical.
 
+The buffer is also the SINK of the fused step: ``wrapper.attach_sink(buffer)`` makes
+``TorchSelfPlayWrapper.step`` write the next observation / mask into row ``ptr + 1`` and the rewards / terminated flags
+into row ``ptr`` directly (``row(t)``, ``step_outputs()``), and ``add`` skips every field it is handed back as its own
+row -- the reference's loop (alg/ppo.py:93-108) runs unchanged while the 7 ``copy_`` of rollout_buffer.py:47-58 shrink to
+the small per-env vectors.  For that the storage survives ``reset()`` (zeroed in place, not reallocated).
+
 This directory has no ``__init__.py`` on purpose: ``alg`` is a namespace package in the reference too, so
 with ``rl-selfplay-mnk_amd/`` ahead of the reference's ``src/`` on ``sys.path`` this module replaces
 ``alg.rollout_buffer`` while ``alg.ppo`` etc. keep resolving to the reference.
@@ -16,27 +22,58 @@ import torch
 import mnk_hip
 
 
+def _same_storage(dst: torch.Tensor, src) -> bool:
+    """is ``src`` the very row ``dst`` (written in place by the fused step)?"""
+    return (isinstance(src, torch.Tensor) and src.data_ptr() == dst.data_ptr() and src.dtype == dst.dtype
+            and src.shape == dst.shape and src.device == dst.device and src.is_contiguous())
+
+
+def _put(dst: torch.Tensor, src) -> int:
+    """dst <- src unless src is dst; returns the bytes copied"""
+    if _same_storage(dst, src):
+        return 0
+    dst.copy_(src)
+    return dst.numel() * dst.element_size()
+
+
 class RolloutBuffer:
-    def __init__(self, n_steps, num_envs, obs_shape, action_dim, device="cpu"):
+    def __init__(self, n_steps, num_envs, obs_shape, action_dim, device="cpu", obs_dtype=torch.float32):
         self.n_steps = n_steps
         self.num_envs = num_envs
         self.obs_shape = obs_shape
         self.action_dim = action_dim
         self.device = device
+        self.obs_dtype = obs_dtype  # float32 = the reference's; bfloat16 / uint8: the env's opt-in narrow observations
+        self.observations = None
+        self.copied_bytes = 0  # bytes ``add`` really copied so far (fields written in place by the fused step cost none)
         if torch.device(device).type != "cuda":
             raise RuntimeError("RolloutBuffer: this is the MI355X implementation (GAE runs in a HIP kernel); "
                                "it needs a GPU device")
         mnk_hip.load()
         self.reset()
 
+    _FIELDS = ("observations", "actions", "log_probs", "rewards", "values", "returns", "advantages", "dones",
+               "action_masks")
+
     def reset(self):
-        """reference rollout_buffer.py:13-45: all fields zeroed, write pointer at 0"""
+        """reference rollout_buffer.py:13-45: all fields zeroed, write pointer at 0.  The reference allocates fresh
+        tensors every time; here the storage is allocated once and zeroed in place afterwards, so rows handed out to
+        the fused step (``attach_sink``) stay valid across ``PPOAgent.learn`` calls."""
         t, n, dev = self.n_steps, self.num_envs, self.device
+        if self.observations is not None:
+            for name in self._FIELDS:
+                getattr(self, name).zero_()
+            self.ptr = 0
+            return
 
-        def field(*shape, dtype=torch.float32):
-            return torch.zeros((t, n) + shape, dtype=dtype, device=dev)
+        def field(*shape, dtype=torch.float32, rows=t):
+            return torch.zeros((rows, n) + shape, dtype=dtype, device=dev)
 
-        self.observations = field(*self.obs_shape)
+        # one row more than n_steps behind observations / action_masks: the spill row that takes the observation
+        # following the last step (PPOAgent._last_obs).  The public fields are views of the first n_steps rows.
+        self._obs_store = field(*self.obs_shape, dtype=self.obs_dtype, rows=t + 1)
+        self._mask_store = field(self.action_dim, dtype=torch.bool, rows=t + 1)
+        self.observations = self._obs_store[:t]
         self.actions = field(dtype=torch.long)
         self.log_probs = field()
         self.rewards = field()
@@ -44,21 +81,48 @@ class RolloutBuffer:
         self.returns = field()
         self.advantages = field()
         self.dones = field(dtype=torch.bool)
-        self.action_masks = field(self.action_dim, dtype=torch.bool)
+        self.action_masks = self._mask_store[:t]
         self.ptr = 0
 
+    # ------------------------------------------------------------------ the sink of the fused step
+    def row(self, t: int) -> dict:
+        """Views of row ``t`` of every per-step field (``t == n_steps``: the spill row, observation and mask only): what
+        ``TorchSelfPlayWrapper.step(actions, out=...)`` and ``mnk_sample_logits`` can write in place."""
+        if not 0 <= t <= self.n_steps:
+            raise IndexError(f"row {t} of a buffer of {self.n_steps} steps")
+        out = {"observation": self._obs_store[t], "action_mask": self._mask_store[t]}
+        if t < self.n_steps:
+            out.update(actions=self.actions[t], log_probs=self.log_probs[t], rewards=self.rewards[t],
+                       values=self.values[t], dones=self.dones[t], terminated=self.dones[t])
+        return out
+
+    def reset_outputs(self):
+        """where ``wrapper.reset()`` puts the first observation: the row the next ``add`` fills"""
+        if self.ptr >= self.n_steps:
+            return None
+        r = self.row(self.ptr)
+        return {"observation": r["observation"], "action_mask": r["action_mask"]}
+
+    def step_outputs(self):
+        """where ``wrapper.step()`` puts its outputs while the write pointer stands at row t: next observation / mask
+        -> row t+1 (the spill row after the last step), rewards / terminated -> row t"""
+        t = self.ptr
+        if t >= self.n_steps:
+            return None
+        nxt = self.row(t + 1)
+        return {"observation": nxt["observation"], "action_mask": nxt["action_mask"], "rewards": self.rewards[t],
+                "terminated": self.dones[t]}
+
     def add(self, obs, action, reward, value, log_prob, done, action_mask):
-        """reference rollout_buffer.py:47-58"""
+        """reference rollout_buffer.py:47-58; a field that already IS this row (the fused step wrote it in place) is
+        not copied"""
         if self.ptr >= self.n_steps:
             raise IndexError("Buffer was full.")
         row = self.ptr
-        self.observations[row].copy_(obs)
-        self.actions[row].copy_(action)
-        self.rewards[row].copy_(reward)
-        self.values[row].copy_(value.view(-1))
-        self.log_probs[row].copy_(log_prob)
-        self.dones[row].copy_(done)
-        self.action_masks[row].copy_(action_mask)
+        self.copied_bytes += (_put(self.observations[row], obs) + _put(self.actions[row], action) +
+                              _put(self.rewards[row], reward) + _put(self.values[row], value.view(-1)) +
+                              _put(self.log_probs[row], log_prob) + _put(self.dones[row], done) +
+                              _put(self.action_masks[row], action_mask))
         self.ptr += 1
 
     def compute_advantages_and_returns(self, last_values, gamma=0.99, gae_lambda=0.95):

@@ -108,60 +108,45 @@ __device__ __forceinline__ uint32_t mnk_stage_bit(const uint32_t* st32, uint32_t
   return (st32[(entry >> 5) + el] >> (entry & 31u)) & 1u;
 }
 
-// obs slab of this workgroup: nb envs x 2C floats starting at dst (16-byte aligned when vec)
-__device__ __forceinline__ void mnk_emit_obs(const MnkStage& s, const MnkGeom& g, int nb, float* dst, bool vec,
-                                             int tid, int nthreads) {
-  const uint32_t* st32 = s.words;
-  const uint32_t row = 2u * (uint32_t)g.C;
-  const uint32_t total = (uint32_t)nb * row;
-  const uint32_t nvec = vec ? (total >> 2) : 0u;
-  for (uint32_t q = tid; q < nvec; q += nthreads) {
-    const uint32_t e = q << 2;
-    uint32_t el = mnk_div(e, g.magic_2C);
-    uint32_t rem = e - el * row;
-    float v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (rem == row) { rem = 0; ++el; }
-      v[j] = (float)mnk_stage_bit(st32, s.tab_obs[rem], el);
-      ++rem;
-    }
-    reinterpret_cast<float4*>(dst)[q] = make_float4(v[0], v[1], v[2], v[3]);
-  }
-  for (uint32_t e = (nvec << 2) + tid; e < total; e += nthreads) {
-    const uint32_t el = mnk_div(e, g.magic_2C);
-    dst[e] = (float)mnk_stage_bit(st32, s.tab_obs[e - el * row], el);
-  }
-}
+// bytes per observation cell for MNK_OBS_F32 / MNK_OBS_BF16 / MNK_OBS_U8
+__host__ __device__ inline int mnk_obs_bytes(int obs_dtype) { return obs_dtype == MNK_OBS_F32 ? 4 : (obs_dtype == MNK_OBS_BF16 ? 2 : 1); }
+__host__ __device__ inline bool mnk_obs_dtype_ok(int obs_dtype) { return obs_dtype >= MNK_OBS_F32 && obs_dtype <= MNK_OBS_U8; }
 
-// mask slab: nb envs x C bytes starting at dst
-__device__ __forceinline__ void mnk_emit_mask(const MnkStage& s, const MnkGeom& g, int nb, uint8_t* dst, bool vec,
-                                              int tid, int nthreads) {
+// Table form (any board): a slab of nb rows x `row` cells starting at dst (16-byte aligned when vec), EB bytes per
+// cell -- 4: f32 1.0 / 0.0 (observation), 2: bf16 1.0 / 0.0, 1: byte 1 / 0 (u8 observation, bool mask).  `tab` holds
+// one entry per cell of a row (tab_obs: 2C entries, tab_mask: C entries), magic_row = the magic of `row`.
+template <int EB>
+__device__ __forceinline__ void mnk_emit_table(const MnkStage& s, const uint32_t* tab, uint32_t row, uint32_t magic_row,
+                                               int nb, void* dst, bool vec, int tid, int nthreads) {
+  constexpr uint32_t PER = 16 / EB, PW = 4 / EB;  // cells per 16-byte vector / per 32-bit word
+  constexpr uint32_t ONE = EB == 4 ? 0x3F800000u : (EB == 2 ? 0x3F80u : 1u);
   const uint32_t* st32 = s.words;
-  const uint32_t row = (uint32_t)g.C;
   const uint32_t total = (uint32_t)nb * row;
-  const uint32_t nvec = vec ? (total >> 4) : 0u;
+  const uint32_t nvec = vec ? total / PER : 0u;
   for (uint32_t q = tid; q < nvec; q += nthreads) {
-    const uint32_t e = q << 4;
-    uint32_t el = mnk_div(e, g.magic_C);
+    const uint32_t e = q * PER;
+    uint32_t el = mnk_div(e, magic_row);
     uint32_t rem = e - el * row;
     uint32_t out[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       uint32_t acc = 0;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
+      for (uint32_t b = 0; b < PW; ++b) {
         if (rem == row) { rem = 0; ++el; }
-        acc |= mnk_stage_bit(st32, s.tab_mask[rem], el) << (8 * b);
+        acc |= (mnk_stage_bit(st32, tab[rem], el) * ONE) << (8 * EB * b);
         ++rem;
       }
       out[j] = acc;
     }
     reinterpret_cast<uint4*>(dst)[q] = make_uint4(out[0], out[1], out[2], out[3]);
   }
-  for (uint32_t e = (nvec << 4) + tid; e < total; e += nthreads) {
-    const uint32_t el = mnk_div(e, g.magic_C);
-    dst[e] = (uint8_t)mnk_stage_bit(st32, s.tab_mask[e - el * row], el);
+  for (uint32_t e = nvec * PER + tid; e < total; e += nthreads) {
+    const uint32_t el = mnk_div(e, magic_row);
+    const uint32_t v = mnk_stage_bit(st32, tab[e - el * row], el) * ONE;
+    if (EB == 4) reinterpret_cast<uint32_t*>(dst)[e] = v;
+    else if (EB == 2) reinterpret_cast<uint16_t*>(dst)[e] = (uint16_t)v;
+    else reinterpret_cast<uint8_t*>(dst)[e] = (uint8_t)v;
   }
 }
 
@@ -210,50 +195,51 @@ __device__ __forceinline__ uint32_t mnk_seg_bits(const uint32_t* segs, int SW, u
 // 4 cells (low nibble) -> 4 bytes of 0 / 1
 __device__ __forceinline__ uint32_t mnk_spread4(uint32_t nib) { return ((nib & 0xFu) * 0x00204081u) & 0x01010101u; }
 
-template <int NW, int CN>
-__device__ __forceinline__ void mnk_emit_obs_packed(const MnkStage& s, const MnkGeom& g, int nb, float* dst, bool vec,
-                                                    int tid, int nthreads) {
-  constexpr int MAXROWS = 32 * NW / (CN + 1), CW = (MAXROWS * CN + 31) / 32, SW = (CW + 1) | 1;
-  const uint32_t C = (uint32_t)g.C, total = (uint32_t)nb * 2u * C;
-  const uint32_t nvec = vec ? (total >> 2) : 0u;
-  for (uint32_t q = tid; q < nvec; q += nthreads) {
-    const uint32_t e = q << 2, sg = mnk_div(e, g.magic_C), pos = e - sg * C;
-    const uint32_t b = mnk_spread4(mnk_seg_bits<4>(s.segs, SW, sg, pos, C));
-    // (wave-uniform slab base + 32-bit lane offset: global_store ... s[base])
-    *reinterpret_cast<float4*>((char*)dst + (uint64_t)(q << 4)) =
-        make_float4((float)(b & 0xFFu), (float)((b >> 8) & 0xFFu), (float)((b >> 16) & 0xFFu), (float)(b >> 24));
-  }
-  for (uint32_t e = (nvec << 2) + tid; e < total; e += nthreads) {
-    const uint32_t sg = mnk_div(e, g.magic_C), pos = e - sg * C;
-    dst[e] = (float)((s.segs[(size_t)sg * SW + (pos >> 5)] >> (pos & 31u)) & 1u);
-  }
-}
+// 8 cells (low byte) -> 4 words of two bf16 1.0 / 0.0 each
+__device__ __forceinline__ uint32_t mnk_spread_bf16x2(uint32_t two) { return ((two & 1u) | ((two & 2u) << 15)) * 0x3F80u; }
 
-template <int NW, int CN>
-__device__ __forceinline__ void mnk_emit_mask_packed(const MnkStage& s, const MnkGeom& g, int B, int nb, uint8_t* dst,
-                                                     bool vec, int tid, int nthreads) {
+// Packed form: `total` cells = consecutive segments of C valid bits each (segs: 2 per env for the observation, 1 per
+// env for the legal mask), EB bytes per cell as in mnk_emit_table; 16 / EB cells per 16-byte store.
+template <int NW, int CN, int EB>
+__device__ __forceinline__ void mnk_emit_packed(const uint32_t* segs, const MnkGeom& g, uint32_t total, void* dst, bool vec,
+                                                int tid, int nthreads) {
   constexpr int MAXROWS = 32 * NW / (CN + 1), CW = (MAXROWS * CN + 31) / 32, SW = (CW + 1) | 1;
-  const uint32_t* msegs = s.segs + (size_t)(2 * B + 1) * SW;
-  const uint32_t C = (uint32_t)g.C, total = (uint32_t)nb * C;
-  const uint32_t nvec = vec ? (total >> 4) : 0u;
+  constexpr uint32_t PER = 16 / EB;
+  const uint32_t C = (uint32_t)g.C;
+  const uint32_t nvec = vec ? total / PER : 0u;
   for (uint32_t q = tid; q < nvec; q += nthreads) {
-    const uint32_t e = q << 4, sg = mnk_div(e, g.magic_C), pos = e - sg * C;
-    const uint32_t x = mnk_seg_bits<16>(msegs, SW, sg, pos, C);
-    *reinterpret_cast<uint4*>((char*)dst + (uint64_t)(q << 4)) =
-        make_uint4(mnk_spread4(x), mnk_spread4(x >> 4), mnk_spread4(x >> 8), mnk_spread4(x >> 12));
+    const uint32_t e = q * PER, sg = mnk_div(e, g.magic_C), pos = e - sg * C;
+    const uint32_t x = mnk_seg_bits<(int)PER>(segs, SW, sg, pos, C);
+    // (wave-uniform slab base + 32-bit lane offset: global_store ... s[base])
+    char* at = (char*)dst + (uint64_t)(q << 4);
+    if constexpr (EB == 4) {
+      const uint32_t b = mnk_spread4(x);
+      *reinterpret_cast<float4*>(at) =
+          make_float4((float)(b & 0xFFu), (float)((b >> 8) & 0xFFu), (float)((b >> 16) & 0xFFu), (float)(b >> 24));
+    } else if constexpr (EB == 2) {
+      *reinterpret_cast<uint4*>(at) = make_uint4(mnk_spread_bf16x2(x), mnk_spread_bf16x2(x >> 2), mnk_spread_bf16x2(x >> 4),
+                                                 mnk_spread_bf16x2(x >> 6));
+    } else {
+      *reinterpret_cast<uint4*>(at) = make_uint4(mnk_spread4(x), mnk_spread4(x >> 4), mnk_spread4(x >> 8), mnk_spread4(x >> 12));
+    }
   }
-  for (uint32_t e = (nvec << 4) + tid; e < total; e += nthreads) {
+  for (uint32_t e = nvec * PER + tid; e < total; e += nthreads) {
     const uint32_t sg = mnk_div(e, g.magic_C), pos = e - sg * C;
-    dst[e] = (uint8_t)((msegs[(size_t)sg * SW + (pos >> 5)] >> (pos & 31u)) & 1u);
+    const uint32_t bit = (segs[(size_t)sg * SW + (pos >> 5)] >> (pos & 31u)) & 1u;
+    if (EB == 4) reinterpret_cast<float*>(dst)[e] = (float)bit;
+    else if (EB == 2) reinterpret_cast<uint16_t*>(dst)[e] = (uint16_t)(bit * 0x3F80u);
+    else reinterpret_cast<uint8_t*>(dst)[e] = (uint8_t)bit;
   }
 }
 
 // The write-out of a workgroup whose stage has been filled by mnk_stage_put: call from ALL threads of the workgroup
-// under a workgroup-uniform condition (it synchronises).  obs / mask may be NULL.
+// under a workgroup-uniform condition (it synchronises).  obs / mask may be NULL; they point at the workgroup's slab
+// (obs: nb rows of 2C cells of mnk_obs_bytes(obs_dtype) bytes; mask: nb rows of C bytes).
 template <int NW, int CN, int CK>
-__device__ __forceinline__ void mnk_write_out(const MnkStage& s, const MnkGeom& g, int B, int nb, float* obs, uint8_t* mask,
-                                              int vec_ok, int tid, int nthreads) {
+__device__ __forceinline__ void mnk_write_out(const MnkStage& s, const MnkGeom& g, int B, int nb, void* obs, int obs_dtype,
+                                              uint8_t* mask, int vec_ok, int tid, int nthreads) {
   __syncthreads();  // the stage is complete
+  const bool ovec = vec_ok & 1, mvec = (vec_ok >> 1) & 1;
   if constexpr (CN != 0 && NW >= 3) {
     if (mnk_geom_packed(CN, CK, NW, g.C)) {
       // the pad segments that follow the last channel / legal segment: read (never used) by the last groups
@@ -264,11 +250,26 @@ __device__ __forceinline__ void mnk_write_out(const MnkStage& s, const MnkGeom& 
       }
       for (int t = tid; t < 3 * B; t += nthreads) mnk_stage_squeeze<NW, CN>(s, B, t);
       __syncthreads();
-      if (obs) mnk_emit_obs_packed<NW, CN>(s, g, nb, obs, vec_ok & 1, tid, nthreads);
-      if (mask) mnk_emit_mask_packed<NW, CN>(s, g, B, nb, mask, (vec_ok >> 1) & 1, tid, nthreads);
+      const uint32_t cells = (uint32_t)nb * 2u * (uint32_t)g.C;
+      if (obs) {
+        if (obs_dtype == MNK_OBS_F32) mnk_emit_packed<NW, CN, 4>(s.segs, g, cells, obs, ovec, tid, nthreads);
+        else if (obs_dtype == MNK_OBS_BF16) mnk_emit_packed<NW, CN, 2>(s.segs, g, cells, obs, ovec, tid, nthreads);
+        else mnk_emit_packed<NW, CN, 1>(s.segs, g, cells, obs, ovec, tid, nthreads);
+      }
+      if (mask) mnk_emit_packed<NW, CN, 1>(s.segs + (size_t)(2 * B + 1) * SW, g, (uint32_t)nb * (uint32_t)g.C, mask, mvec, tid, nthreads);
       return;
     }
   }
-  if (obs) mnk_emit_obs(s, g, nb, obs, vec_ok & 1, tid, nthreads);
-  if (mask) mnk_emit_mask(s, g, nb, mask, (vec_ok >> 1) & 1, tid, nthreads);
+  if (obs) {
+    const uint32_t row = 2u * (uint32_t)g.C;
+    if (obs_dtype == MNK_OBS_F32) mnk_emit_table<4>(s, s.tab_obs, row, g.magic_2C, nb, obs, ovec, tid, nthreads);
+    else if (obs_dtype == MNK_OBS_BF16) mnk_emit_table<2>(s, s.tab_obs, row, g.magic_2C, nb, obs, ovec, tid, nthreads);
+    else mnk_emit_table<1>(s, s.tab_obs, row, g.magic_2C, nb, obs, ovec, tid, nthreads);
+  }
+  if (mask) mnk_emit_table<1>(s, s.tab_mask, (uint32_t)g.C, g.magic_C, nb, mask, mvec, tid, nthreads);
+}
+
+// the workgroup's slab of an observation array: row env0 of rows of 2C cells
+__device__ __forceinline__ void* mnk_obs_slab(void* obs, int obs_dtype, int64_t row0, int C) {
+  return obs ? (void*)((char*)obs + row0 * 2 * C * mnk_obs_bytes(obs_dtype)) : nullptr;
 }

@@ -29,10 +29,21 @@ __global__ void k_reset_mask(uint64_t* planes, uint32_t* meta, int64_t N, int W,
 }
 
 // ------------------------------------------------------------------ step (full batch, fused write-out)
-template <int NW, int CN, int CK>
+// DRAW: the lane draws its own uniformly random legal move (RandomPolicy, policy.py:18-29) instead of reading
+// actions[i] -- mnk_step_random, BASELINE.json config 2 in one launch per ply
+struct MnkDraw {
+  uint64_t seed, step;
+  const uint64_t* step_dev;
+  int64_t env_id0;
+  uint32_t stream_id;
+  int64_t* actions_out;  // optional: the moves played
+};
+
+template <int NW, int CN, int CK, bool DRAW>
 __global__ void __launch_bounds__(256)
-k_step_full(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions, float* rewards,
-            uint8_t* dones, uint8_t* legal_mask, float* obs, int32_t* err, uint32_t flags, int vec_ok, int envs_per_block) {
+k_step_full(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions, MnkDraw draw, float* rewards,
+            uint8_t* dones, uint8_t* legal_mask, void* obs, int obs_dtype, int32_t* err, uint32_t flags, int vec_ok,
+            int envs_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
   const int64_t env0 = (int64_t)blockIdx.x * B;
@@ -43,7 +54,15 @@ k_step_full(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_
   if (tid < B && i < N) {
     MnkEnv<NW> e;
     env_load<NW>(e, planes, meta, N, g.W, i);
-    MnkPly ply = env_play<NW, CN, CK>(g, e, actions[i], (flags & MNK_STEP_STRICT) != 0);
+    MnkPly ply;
+    if constexpr (DRAW) {
+      const uint64_t step = draw.step + (draw.step_dev ? *draw.step_dev : 0ull);
+      const int a = env_pick_legal<NW, CN>(g, e, mnk_rand_u32(draw.seed, (uint64_t)(draw.env_id0 + i), step, draw.stream_id));
+      if (draw.actions_out) draw.actions_out[i] = a;
+      ply = env_play<NW, CN, CK, true>(g, e, a, false);
+    } else {
+      ply = env_play<NW, CN, CK>(g, e, actions[i], (flags & MNK_STEP_STRICT) != 0);
+    }
     if ((flags & MNK_STEP_AUTORESET) && ply.done) env_clear<NW>(e);  // :34-44 for the envs of nonzero(done)
     if (ply.err) mnk_report(err, ply.err, i);
     else env_store<NW>(e, planes, meta, N, g.W, i);
@@ -54,7 +73,7 @@ k_step_full(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_
   if (emit) {
     const int64_t left = N - env0;
     const int nb = left < B ? (int)left : B;
-    mnk_write_out<NW, CN, CK>(st, g, B, nb, obs ? obs + env0 * 2 * g.C : nullptr,
+    mnk_write_out<NW, CN, CK>(st, g, B, nb, mnk_obs_slab(obs, obs_dtype, env0, g.C), obs_dtype,
                               legal_mask ? legal_mask + env0 * g.C : nullptr, vec_ok, tid, NT);
   }
 }
@@ -80,10 +99,18 @@ k_step_subset(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int6
 }
 
 // ------------------------------------------------------------------ observe / unpack
+// the view (channel 0, channel 1) of env i as packed planes u64[2][W][N]: what PackedRolloutBuffer stores
+template <int NW>
+__device__ __forceinline__ void mnk_packed_put(uint64_t* packed, int64_t N, int W, int64_t i, const uint32_t (&ch0)[NW],
+                                               const uint32_t (&ch1)[NW]) {
+  plane_store<NW>(ch0, packed, N, W, i);
+  plane_store<NW>(ch1, packed + (int64_t)W * N, N, W, i);
+}
+
 template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
-k_observe(MnkGeom g, const uint64_t* planes, int64_t N, const int64_t* flip_side, float* obs,
-          uint8_t* legal_mask, int fix_empty, int vec_ok, int envs_per_block) {
+k_observe(MnkGeom g, const uint64_t* planes, int64_t N, const int64_t* flip_side, void* obs, int obs_dtype,
+          uint8_t* legal_mask, int fix_empty, uint64_t* packed_obs, int vec_ok, int envs_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
   const int64_t env0 = (int64_t)blockIdx.x * B;
@@ -97,10 +124,12 @@ k_observe(MnkGeom g, const uint64_t* planes, int64_t N, const int64_t* flip_side
     const bool flip = flip_side && flip_side[i] == 1;  // wrapper:104-106
     if (flip) mnk_stage_put<NW>(st, g, B, tid, p1, p0, fix_empty != 0);
     else mnk_stage_put<NW>(st, g, B, tid, p0, p1, fix_empty != 0);
+    if (packed_obs) mnk_packed_put<NW>(packed_obs, N, g.W, i, flip ? p1 : p0, flip ? p0 : p1);
   }
+  if (!obs && !legal_mask) return;  // packed planes only (workgroup-uniform)
   const int64_t left = N - env0;
   const int nb = left < B ? (int)left : B;
-  mnk_write_out<NW, CN, CK>(st, g, B, nb, obs ? obs + env0 * 2 * g.C : nullptr,
+  mnk_write_out<NW, CN, CK>(st, g, B, nb, mnk_obs_slab(obs, obs_dtype, env0, g.C), obs_dtype,
                             legal_mask ? legal_mask + env0 * g.C : nullptr, vec_ok, tid, NT);
 }
 
@@ -209,8 +238,8 @@ __global__ void __launch_bounds__(256)
 k_selfplay_pre(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions,
                const uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
                uint64_t step, const uint64_t* step_dev, int64_t env_id0, float* rewards, uint8_t* terminated,
-               uint8_t* sp_flags, float* opp_obs, uint8_t* opp_mask, int32_t* err, uint32_t flags, int vec_ok,
-               int envs_per_block) {
+               uint8_t* sp_flags, void* opp_obs, int obs_dtype, uint8_t* opp_mask, int32_t* err, uint32_t flags,
+               int vec_ok, int envs_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   if (step_dev) step += *step_dev;
   const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
@@ -241,7 +270,7 @@ k_selfplay_pre(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int
   if (emit) {
     const int64_t left = N - env0;
     const int nb = left < B ? (int)left : B;
-    mnk_write_out<NW, CN, CK>(st, g, B, nb, opp_obs ? opp_obs + env0 * 2 * g.C : nullptr,
+    mnk_write_out<NW, CN, CK>(st, g, B, nb, mnk_obs_slab(opp_obs, obs_dtype, env0, g.C), obs_dtype,
                               opp_mask ? opp_mask + env0 * g.C : nullptr, vec_ok, tid, NT);
   }
 }
@@ -250,8 +279,8 @@ template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
 k_selfplay_post(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* opp_actions,
                 const uint8_t* sp_flags, const int64_t* agent_side, float* rewards, uint8_t* terminated,
-                uint8_t* pending, float* obs, uint8_t* legal_mask, int32_t* err, MnkEpisodes ep, uint32_t flags,
-                int vec_ok, int envs_per_block) {
+                uint8_t* pending, void* obs, int obs_dtype, uint8_t* legal_mask, uint64_t* packed_obs, int32_t* err,
+                MnkEpisodes ep, uint32_t flags, int vec_ok, int envs_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   __shared__ unsigned int lds_ep[MNK_STATS_COUNTERS];
   const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
@@ -283,15 +312,17 @@ k_selfplay_post(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const in
     }
     pending[i] = term ? 1 : 0;  // :65
     if (ep.stats) mnk_ep_account(ep, i, rew, term, lds_ep);
+    const bool white = agent_side[i] == 1;  // :104-106
     if (emit) {
-      if (agent_side[i] == 1) mnk_stage_put<NW>(st, g, B, tid, e.p[1], e.p[0], true);  // :104-106
+      if (white) mnk_stage_put<NW>(st, g, B, tid, e.p[1], e.p[0], true);
       else mnk_stage_put<NW>(st, g, B, tid, e.p[0], e.p[1], true);
     }
+    if (packed_obs) mnk_packed_put<NW>(packed_obs, N, g.W, i, white ? e.p[1] : e.p[0], white ? e.p[0] : e.p[1]);
   }
   if (emit) {  // (synchronises: the episode counters in LDS are complete after it, too)
     const int64_t left = N - env0;
     const int nb = left < B ? (int)left : B;
-    mnk_write_out<NW, CN, CK>(st, g, B, nb, obs ? obs + env0 * 2 * g.C : nullptr,
+    mnk_write_out<NW, CN, CK>(st, g, B, nb, mnk_obs_slab(obs, obs_dtype, env0, g.C), obs_dtype,
                               legal_mask ? legal_mask + env0 * g.C : nullptr, vec_ok, tid, NT);
   } else if (ep.stats) {
     __syncthreads();
@@ -305,8 +336,8 @@ __global__ void __launch_bounds__(256)
 k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions,
                        uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
                        uint64_t step, const uint64_t* step_dev, int64_t env_id0, float* rewards,
-                       uint8_t* terminated, float* obs, uint8_t* legal_mask, int32_t* err, MnkEpisodes ep,
-                       uint32_t flags, int vec_ok, int envs_per_block) {
+                       uint8_t* terminated, void* obs, int obs_dtype, uint8_t* legal_mask, uint64_t* packed_obs,
+                       int32_t* err, MnkEpisodes ep, uint32_t flags, int vec_ok, int envs_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   if (step_dev) step += *step_dev;
   __shared__ unsigned int lds_ep[MNK_STATS_COUNTERS];
@@ -346,11 +377,12 @@ k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, c
       if (side == 1) mnk_stage_put<NW>(st, g, B, tid, e.p[1], e.p[0], true);
       else mnk_stage_put<NW>(st, g, B, tid, e.p[0], e.p[1], true);
     }
+    if (packed_obs) mnk_packed_put<NW>(packed_obs, N, g.W, i, side == 1 ? e.p[1] : e.p[0], side == 1 ? e.p[0] : e.p[1]);
   }
   if (emit) {  // (synchronises: the episode counters in LDS are complete after it, too)
     const int64_t left = N - env0;
     const int nb = left < B ? (int)left : B;
-    mnk_write_out<NW, CN, CK>(st, g, B, nb, obs ? obs + env0 * 2 * g.C : nullptr,
+    mnk_write_out<NW, CN, CK>(st, g, B, nb, mnk_obs_slab(obs, obs_dtype, env0, g.C), obs_dtype,
                               legal_mask ? legal_mask + env0 * g.C : nullptr, vec_ok, tid, NT);
   } else if (ep.stats) {
     __syncthreads();
@@ -361,7 +393,7 @@ k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, c
 // ------------------------------------------------------------------ records -> RolloutBuffer layout
 template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
-k_unpack_records(MnkGeom g, const uint64_t* rec_planes, const uint32_t* rec_meta, int64_t N, float* obs,
+k_unpack_records(MnkGeom g, const uint64_t* rec_planes, const uint32_t* rec_meta, int64_t N, void* obs, int obs_dtype,
                  uint8_t* masks, int64_t* actions, float* rewards, uint8_t* dones, int vec_ok, int envs_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
@@ -387,8 +419,8 @@ k_unpack_records(MnkGeom g, const uint64_t* rec_planes, const uint32_t* rec_meta
     const int64_t left = N - env0;
     const int nb = left < B ? (int)left : B;
     const int64_t row0 = t * N + env0;
-    mnk_write_out<NW, CN, CK>(st, g, B, nb, obs ? obs + row0 * 2 * g.C : nullptr, masks ? masks + row0 * g.C : nullptr,
-                              vec_ok, tid, NT);
+    mnk_write_out<NW, CN, CK>(st, g, B, nb, mnk_obs_slab(obs, obs_dtype, row0, g.C), obs_dtype,
+                              masks ? masks + row0 * g.C : nullptr, vec_ok, tid, NT);
   }
 }
 
@@ -400,8 +432,8 @@ k_unpack_records(MnkGeom g, const uint64_t* rec_planes, const uint32_t* rec_meta
 // writes its contiguous slab of observations and masks through the LDS stage.
 template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
-k_gather_obs(MnkGeom g, const uint64_t* planes, int64_t T, int64_t N, const int64_t* idx, int64_t B_total, float* obs,
-             uint8_t* legal_mask, int fix_empty, int32_t* err, int vec_ok, int envs_per_block) {
+k_gather_obs(MnkGeom g, const uint64_t* planes, int64_t T, int64_t N, const int64_t* idx, int64_t B_total, void* obs,
+             int obs_dtype, uint8_t* legal_mask, int fix_empty, int32_t* err, int vec_ok, int envs_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
   const int64_t row0 = (int64_t)blockIdx.x * B;
@@ -426,7 +458,7 @@ k_gather_obs(MnkGeom g, const uint64_t* planes, int64_t T, int64_t N, const int6
   }
   const int64_t left = B_total - row0;
   const int nb = left < B ? (int)left : B;
-  mnk_write_out<NW, CN, CK>(st, g, B, nb, obs ? obs + row0 * 2 * g.C : nullptr,
+  mnk_write_out<NW, CN, CK>(st, g, B, nb, mnk_obs_slab(obs, obs_dtype, row0, g.C), obs_dtype,
                             legal_mask ? legal_mask + row0 * g.C : nullptr, vec_ok, tid, NT);
 }
 
@@ -548,25 +580,25 @@ int mnk_reset_mask(uint64_t* planes, uint32_t* meta, int64_t N, int W, const uin
 }
 
 int mnk_observe(const uint64_t* planes, const uint32_t* meta, int64_t N, int m, int n, const int64_t* flip_side,
-                float* obs, uint8_t* legal_mask, int fix_empty_mask, void* stream) {
+                void* obs, int obs_dtype, uint8_t* legal_mask, int fix_empty_mask, uint64_t* packed_obs, void* stream) {
   (void)meta;
   MnkGeom g;
   int rc = mnk_geom_any_k(m, n, &g);
   if (rc != MNK_OK) return rc;
-  if (!planes || N < 0) return MNK_EINVAL;
-  if (N == 0 || (!obs && !legal_mask)) return MNK_OK;
+  if (!planes || N < 0 || !mnk_obs_dtype_ok(obs_dtype)) return MNK_EINVAL;
+  if (N == 0 || (!obs && !legal_mask && !packed_obs)) return MNK_OK;
   const int B = mnk_block_envs(N);
   const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
   const size_t lds = mnk_stage_bytes(g.NW, g.C, B, g.n, g.k);
   const dim3 grid((unsigned)((N + B - 1) / B));
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_observe), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, planes, N,
-                                         flip_side, obs, legal_mask, fix_empty_mask, vec_ok, B));
+                                         flip_side, obs, obs_dtype, legal_mask, fix_empty_mask, packed_obs, vec_ok, B));
   return mnk_launch_status("observe");
 }
 
 int mnk_unpack_boards(const uint64_t* planes, float* boards, int64_t N, int m, int n, void* stream) {
   if (!boards) return MNK_EINVAL;
-  return mnk_observe(planes, nullptr, N, m, n, nullptr, boards, nullptr, 0, stream);
+  return mnk_observe(planes, nullptr, N, m, n, nullptr, boards, MNK_OBS_F32, nullptr, 0, nullptr, stream);
 }
 
 int mnk_pack_boards(const float* boards, uint64_t* planes, int64_t N, int m, int n, void* stream) {
@@ -581,27 +613,56 @@ int mnk_pack_boards(const float* boards, uint64_t* planes, int64_t N, int m, int
   return mnk_launch_status("pack_boards");
 }
 
-int mnk_step(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const int64_t* actions,
-             const int64_t* active_idx, int64_t A, float* rewards, uint8_t* dones, uint8_t* legal_mask, float* obs,
-             int32_t* err, uint32_t flags, void* stream) {
+// the full-batch step kernel, with the action read from `actions` or (draw != NULL) drawn by the lane itself
+static int mnk_launch_step_full(const MnkGeom& g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions,
+                                const MnkDraw* draw, float* rewards, uint8_t* dones, uint8_t* legal_mask, void* obs,
+                                int obs_dtype, int32_t* err, uint32_t flags, hipStream_t s) {
+  const int B = mnk_block_envs(N);
+  const bool emit = legal_mask || obs;
+  const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
+  const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, g.k) : 0;
+  const dim3 grid((unsigned)((N + B - 1) / B));
+  const MnkDraw none = {0, 0, nullptr, 0, 0, nullptr};
+  if (draw)
+    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_full<NW, CN, CK, true>), grid, dim3(mnk_block_threads()), lds, s,
+                                       g, planes, meta, N, actions, *draw, rewards, dones, legal_mask, obs, obs_dtype, err,
+                                       flags, vec_ok, B));
+  else
+    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_full<NW, CN, CK, false>), grid, dim3(mnk_block_threads()), lds, s,
+                                       g, planes, meta, N, actions, none, rewards, dones, legal_mask, obs, obs_dtype, err,
+                                       flags, vec_ok, B));
+  return mnk_launch_status(draw ? "step_random" : "step");
+}
+
+int mnk_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, uint64_t seed, uint64_t step,
+                    const uint64_t* step_dev, int64_t env_id0, int stream_id, int64_t* actions_out, float* rewards,
+                    uint8_t* dones, uint8_t* legal_mask, void* obs, int obs_dtype, uint32_t flags, void* stream) {
   MnkGeom g;
   int rc = mnk_check_geom(m, n, k, &g);
   if (rc != MNK_OK) return rc;
-  if (!planes || !meta || !rewards || !dones || N < 0 || A < 0 || (A > 0 && !actions)) return MNK_EINVAL;
+  if (!planes || !meta || !rewards || !dones || N < 0 || stream_id < 0 || stream_id > 255 || !mnk_obs_dtype_ok(obs_dtype))
+    return MNK_EINVAL;
+  if (flags & ~MNK_STEP_AUTORESET) return MNK_EINVAL;  // a drawn move is legal by construction: nothing to be strict about
+  if (N == 0) return MNK_OK;
+  const MnkDraw draw = {seed, step, step_dev, env_id0, (uint32_t)stream_id, actions_out};
+  return mnk_launch_step_full(g, planes, meta, N, nullptr, &draw, rewards, dones, legal_mask, obs, obs_dtype, nullptr,
+                              flags, (hipStream_t)stream);
+}
+
+int mnk_step(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const int64_t* actions,
+             const int64_t* active_idx, int64_t A, float* rewards, uint8_t* dones, uint8_t* legal_mask, void* obs,
+             int obs_dtype, int32_t* err, uint32_t flags, void* stream) {
+  MnkGeom g;
+  int rc = mnk_check_geom(m, n, k, &g);
+  if (rc != MNK_OK) return rc;
+  if (!planes || !meta || !rewards || !dones || N < 0 || A < 0 || (A > 0 && !actions) || !mnk_obs_dtype_ok(obs_dtype))
+    return MNK_EINVAL;
   if (!active_idx && A != N) return MNK_EINVAL;
   if (active_idx && (flags & MNK_STEP_AUTORESET)) return MNK_EINVAL;
   if (N == 0) return MNK_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (!active_idx) {
-    const int B = mnk_block_envs(N);
-    const bool emit = legal_mask || obs;
-    const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
-    const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, g.k) : 0;
-    const dim3 grid((unsigned)((N + B - 1) / B));
-    MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_step_full), grid, dim3(mnk_block_threads()), lds, s, g, planes, meta, N, actions,
-                                           rewards, dones, legal_mask, obs, err, flags, vec_ok, B));
-    return mnk_launch_status("step");
-  }
+  if (!active_idx)
+    return mnk_launch_step_full(g, planes, meta, N, actions, nullptr, rewards, dones, legal_mask, obs, obs_dtype, err, flags, s);
   // subset: full-size zero rewards / dones (:75, :79), scatter the active ones, then a full observe
   if (hipMemsetAsync(rewards, 0, (size_t)N * sizeof(float), s) != hipSuccess) return mnk_launch_status("step_subset");
   if (hipMemsetAsync(dones, 0, (size_t)N, s) != hipSuccess) return mnk_launch_status("step_subset");
@@ -613,7 +674,7 @@ int mnk_step(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, c
     rc = mnk_launch_status("step_subset");
     if (rc != MNK_OK) return rc;
   }
-  if (legal_mask || obs) return mnk_observe(planes, meta, N, m, n, nullptr, obs, legal_mask, 0, stream);
+  if (legal_mask || obs) return mnk_observe(planes, meta, N, m, n, nullptr, obs, obs_dtype, legal_mask, 0, nullptr, stream);
   return MNK_OK;
 }
 
@@ -634,11 +695,13 @@ int mnk_sample_legal(const uint64_t* planes, int64_t N, int m, int n, uint64_t s
 int mnk_selfplay_pre(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const int64_t* actions,
                      const uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
                      uint64_t step, const uint64_t* step_dev, int64_t env_id0, float* rewards, uint8_t* terminated,
-                     uint8_t* sp_flags, float* opp_obs, uint8_t* opp_mask, int32_t* err, uint32_t flags, void* stream) {
+                     uint8_t* sp_flags, void* opp_obs, int obs_dtype, uint8_t* opp_mask, int32_t* err, uint32_t flags,
+                     void* stream) {
   MnkGeom g;
   int rc = mnk_check_geom(m, n, k, &g);
   if (rc != MNK_OK) return rc;
-  if (!planes || !meta || !actions || !pending || !agent_side || !rewards || !terminated || !sp_flags || N < 0)
+  if (!planes || !meta || !actions || !pending || !agent_side || !rewards || !terminated || !sp_flags || N < 0 ||
+      !mnk_obs_dtype_ok(obs_dtype))
     return MNK_EINVAL;
   if (N == 0) return MNK_OK;
   const int B = mnk_block_envs(N);
@@ -648,18 +711,19 @@ int mnk_selfplay_pre(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, 
   const dim3 grid((unsigned)((N + B - 1) / B));
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_pre), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, planes, meta,
                                          N, actions, pending, agent_side, forced_side, seed, step, step_dev, env_id0,
-                                         rewards, terminated, sp_flags, opp_obs, opp_mask, err, flags, vec_ok, B));
+                                         rewards, terminated, sp_flags, opp_obs, obs_dtype, opp_mask, err, flags, vec_ok, B));
   return mnk_launch_status("selfplay_pre");
 }
 
 int mnk_selfplay_post(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const int64_t* opp_actions,
                       const uint8_t* sp_flags, const int64_t* agent_side, float* rewards, uint8_t* terminated,
-                      uint8_t* pending, float* obs, uint8_t* legal_mask, int32_t* err, float* ep_return,
-                      int32_t* ep_length, int64_t* ep_stats, uint32_t flags, void* stream) {
+                      uint8_t* pending, void* obs, int obs_dtype, uint8_t* legal_mask, uint64_t* packed_obs, int32_t* err,
+                      float* ep_return, int32_t* ep_length, int64_t* ep_stats, uint32_t flags, void* stream) {
   MnkGeom g;
   int rc = mnk_check_geom(m, n, k, &g);
   if (rc != MNK_OK) return rc;
-  if (!planes || !meta || !opp_actions || !sp_flags || !agent_side || !rewards || !terminated || !pending || N < 0)
+  if (!planes || !meta || !opp_actions || !sp_flags || !agent_side || !rewards || !terminated || !pending || N < 0 ||
+      !mnk_obs_dtype_ok(obs_dtype))
     return MNK_EINVAL;
   if (ep_stats && (!ep_return || !ep_length)) return MNK_EINVAL;
   const MnkEpisodes ep = {ep_return, ep_length, (unsigned long long*)ep_stats};
@@ -671,19 +735,22 @@ int mnk_selfplay_post(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n,
   const dim3 grid((unsigned)((N + B - 1) / B));
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_post), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, planes,
                                          meta, N, opp_actions, sp_flags, agent_side, rewards, terminated, pending, obs,
-                                         legal_mask, err, ep, flags, vec_ok, B));
+                                         obs_dtype, legal_mask, packed_obs, err, ep, flags, vec_ok, B));
   return mnk_launch_status("selfplay_post");
 }
 
 int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const int64_t* actions,
                              uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
                              uint64_t step, const uint64_t* step_dev, int64_t env_id0, float* rewards,
-                             uint8_t* terminated, float* obs, uint8_t* legal_mask, int32_t* err, float* ep_return,
-                             int32_t* ep_length, int64_t* ep_stats, uint32_t flags, void* stream) {
+                             uint8_t* terminated, void* obs, int obs_dtype, uint8_t* legal_mask, uint64_t* packed_obs,
+                             int32_t* err, float* ep_return, int32_t* ep_length, int64_t* ep_stats, uint32_t flags,
+                             void* stream) {
   MnkGeom g;
   int rc = mnk_check_geom(m, n, k, &g);
   if (rc != MNK_OK) return rc;
-  if (!planes || !meta || !actions || !pending || !agent_side || !rewards || !terminated || N < 0) return MNK_EINVAL;
+  if (!planes || !meta || !actions || !pending || !agent_side || !rewards || !terminated || N < 0 ||
+      !mnk_obs_dtype_ok(obs_dtype))
+    return MNK_EINVAL;
   if (ep_stats && (!ep_return || !ep_length)) return MNK_EINVAL;
   const MnkEpisodes ep = {ep_return, ep_length, (unsigned long long*)ep_stats};
   if (N == 0) return MNK_OK;
@@ -694,43 +761,46 @@ int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m,
   const dim3 grid((unsigned)((N + B - 1) / B));
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_step_random), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g,
                                          planes, meta, N, actions, pending, agent_side, forced_side, seed, step,
-                                         step_dev, env_id0, rewards, terminated, obs, legal_mask, err, ep, flags, vec_ok, B));
+                                         step_dev, env_id0, rewards, terminated, obs, obs_dtype, legal_mask, packed_obs, err,
+                                         ep, flags, vec_ok, B));
   return mnk_launch_status("selfplay_step_random");
 }
 
 int mnk_unpack_records(const uint64_t* rec_planes, const uint32_t* rec_meta, int64_t N, int T, int m, int n,
-                       float* obs, uint8_t* masks, int64_t* actions, float* rewards, uint8_t* dones, void* stream) {
+                       void* obs, int obs_dtype, uint8_t* masks, int64_t* actions, float* rewards, uint8_t* dones,
+                       void* stream) {
   MnkGeom g;
   int rc = mnk_geom_any_k(m, n, &g);
   if (rc != MNK_OK) return rc;
-  if (!rec_meta || N < 0 || T < 0 || T > 65535 || ((obs || masks) && !rec_planes)) return MNK_EINVAL;
+  if (!rec_meta || N < 0 || T < 0 || T > 65535 || ((obs || masks) && !rec_planes) || !mnk_obs_dtype_ok(obs_dtype))
+    return MNK_EINVAL;
   if (N == 0 || T == 0) return MNK_OK;
   const int B = mnk_block_envs(N * (int64_t)T);
   const bool emit = obs || masks;
   // slabs start at row t*N + env0: 16-byte alignment of every slab needs N*rowbytes % 16 == 0 too
-  const bool obs_vec = aligned16(obs) && ((N * 2 * g.C * 4) % 16 == 0);
+  const bool obs_vec = aligned16(obs) && ((N * 2 * g.C * mnk_obs_bytes(obs_dtype)) % 16 == 0);
   const bool mask_vec = aligned16(masks) && ((N * g.C) % 16 == 0);
   const int vec_ok = (obs_vec ? 1 : 0) | (mask_vec ? 2 : 0);
   const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, g.k) : 0;
   const dim3 grid((unsigned)((N + B - 1) / B), (unsigned)T);
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_unpack_records), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, rec_planes,
-                                         rec_meta, N, obs, masks, actions, rewards, dones, vec_ok, B));
+                                         rec_meta, N, obs, obs_dtype, masks, actions, rewards, dones, vec_ok, B));
   return mnk_launch_status("unpack_records");
 }
 
 int mnk_gather_obs(const uint64_t* planes, int64_t T, int64_t N, int m, int n, const int64_t* idx, int64_t B,
-                   float* obs, uint8_t* legal_mask, int fix_empty_mask, int32_t* err, void* stream) {
+                   void* obs, int obs_dtype, uint8_t* legal_mask, int fix_empty_mask, int32_t* err, void* stream) {
   MnkGeom g;
   int rc = mnk_geom_any_k(m, n, &g);
   if (rc != MNK_OK) return rc;
-  if (!planes || T < 0 || N < 0 || B < 0 || (B > 0 && !idx)) return MNK_EINVAL;
+  if (!planes || T < 0 || N < 0 || B < 0 || (B > 0 && !idx) || !mnk_obs_dtype_ok(obs_dtype)) return MNK_EINVAL;
   if (B == 0 || (!obs && !legal_mask)) return MNK_OK;
   const int E = mnk_block_envs(B);
   const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
   const size_t lds = mnk_stage_bytes(g.NW, g.C, E, g.n, g.k);
   const dim3 grid((unsigned)((B + E - 1) / E));
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_gather_obs), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g,
-                                     planes, T, N, idx, B, obs, legal_mask, fix_empty_mask, err, vec_ok, E));
+                                     planes, T, N, idx, B, obs, obs_dtype, legal_mask, fix_empty_mask, err, vec_ok, E));
   return mnk_launch_status("gather_obs");
 }
 

@@ -159,7 +159,8 @@ class _CountView(_DenseView):
 class TorchVectorMnkEnv:
     """Batched m,n,k-game on bit-packed boards; surface of reference env:7-119."""
 
-    def __init__(self, m: int, n: int, k: int, num_envs: int, device: str = "cuda", strict: bool = False):
+    def __init__(self, m: int, n: int, k: int, num_envs: int, device: str = "cuda", strict: bool = False,
+                 obs_dtype: torch.dtype = torch.float32):
         assert m >= k and n >= k, f"Board ({m}x{n}) is too small for k={k}"  # reference env:9
         dev = torch.device(device)
         if dev.type != "cuda":
@@ -183,6 +184,10 @@ class TorchVectorMnkEnv:
         self._dev = dev
         self.max_moves = self.m * self.n
         self.strict = bool(strict)
+        # dtype of the observations this env (and a wrapper around it) hands out: float32 is the reference's; bfloat16 /
+        # uint8 are opt-in narrow forms of the same 0 / 1 cells (include/mnk_hip.h MNK_OBS_*), half / a quarter of the bytes
+        mnk_hip.obs_dtype_code(obs_dtype)
+        self.obs_dtype = obs_dtype
         self.words = mnk_hip.state_words(self.m, self.n)
         # packed state; int64 / int32 tensors carry the u64 / u32 bit patterns
         self._planes = torch.zeros((2, self.words, self.num_envs), dtype=torch.int64, device=dev)
@@ -269,7 +274,7 @@ class TorchVectorMnkEnv:
 
     def observe(self) -> Dict[str, torch.Tensor]:
         """reference env:46-53: fresh tensors, absolute planes, row-major legal mask"""
-        obs = torch.empty((self.num_envs, 2, self.m, self.n), dtype=torch.float32, device=self._dev)
+        obs = torch.empty((self.num_envs, 2, self.m, self.n), dtype=self.obs_dtype, device=self._dev)
         mask = torch.empty((self.num_envs, self.max_moves), dtype=torch.bool, device=self._dev)
         self.observe_into(obs, mask)
         return {"observation": obs, "action_mask": mask}
@@ -283,7 +288,7 @@ class TorchVectorMnkEnv:
     def step(self, actions: torch.Tensor) -> Tuple[Dict[str, torch.Tensor], torch.Tensor, torch.Tensor]:
         """reference env:55-58"""
         actions = self._as_actions(actions, self.num_envs)
-        obs = torch.empty((self.num_envs, 2, self.m, self.n), dtype=torch.float32, device=self._dev)
+        obs = torch.empty((self.num_envs, 2, self.m, self.n), dtype=self.obs_dtype, device=self._dev)
         mask = torch.empty((self.num_envs, self.max_moves), dtype=torch.bool, device=self._dev)
         rewards = torch.empty(self.num_envs, dtype=torch.float32, device=self._dev)
         dones = torch.empty(self.num_envs, dtype=torch.bool, device=self._dev)
@@ -294,38 +299,55 @@ class TorchVectorMnkEnv:
         """reference env:60-84: full-size rewards / dones, full observation"""
         idx = torch.as_tensor(_unwrap(active_indices), device=self._dev).to(torch.int64).reshape(-1).contiguous()
         actions = self._as_actions(actions, idx.numel())
-        obs = torch.empty((self.num_envs, 2, self.m, self.n), dtype=torch.float32, device=self._dev)
+        obs = torch.empty((self.num_envs, 2, self.m, self.n), dtype=self.obs_dtype, device=self._dev)
         mask = torch.empty((self.num_envs, self.max_moves), dtype=torch.bool, device=self._dev)
         rewards = torch.empty(self.num_envs, dtype=torch.float32, device=self._dev)
         dones = torch.empty(self.num_envs, dtype=torch.bool, device=self._dev)
         if self.num_envs:
             mnk_hip.call("mnk_step", mnk_hip.ptr(self._planes), mnk_hip.ptr(self._meta), self.num_envs, self.m,
                          self.n, self.k, mnk_hip.ptr(actions), mnk_hip.ptr(idx), idx.numel(), mnk_hip.ptr(rewards),
-                         mnk_hip.ptr(dones), mnk_hip.ptr(mask), mnk_hip.ptr(obs), mnk_hip.ptr(self._err),
-                         self._flags(), self._stream())
+                         mnk_hip.ptr(dones), mnk_hip.ptr(mask), mnk_hip.ptr(obs), mnk_hip.obs_code(obs),
+                         mnk_hip.ptr(self._err), self._flags(), self._stream())
         if self.strict:
             self.check_errors()
         return {"observation": obs, "action_mask": mask}, rewards, dones
 
     # ------------------------------------------------------------------ buffer-reusing forms (graph-capturable)
     def step_into(self, actions, rewards, dones, mask=None, obs=None, autoreset: bool = False) -> None:
-        """``step`` into caller-owned buffers; ``mask`` / ``obs`` may be None to skip them.
+        """``step`` into caller-owned buffers; ``mask`` / ``obs`` may be None to skip them (``obs``: float32,
+        bfloat16 or uint8 -- the kernel writes the dtype it is given).
         One kernel launch, nothing allocated, nothing synchronised (unless ``strict``).
         ``autoreset``: finished games restart in the same launch and ``mask`` / ``obs`` show the fresh boards --
         ``step(a); reset(nonzero(done)); observe()`` of the raw loop as one kernel."""
         if self.num_envs:
             mnk_hip.call("mnk_step", mnk_hip.ptr(self._planes), mnk_hip.ptr(self._meta), self.num_envs, self.m,
                          self.n, self.k, mnk_hip.ptr(actions), None, self.num_envs, mnk_hip.ptr(rewards),
-                         mnk_hip.ptr(dones), mnk_hip.ptr(mask), mnk_hip.ptr(obs), mnk_hip.ptr(self._err),
-                         self._flags() | (mnk_hip.STEP_AUTORESET if autoreset else 0), self._stream())
+                         mnk_hip.ptr(dones), mnk_hip.ptr(mask), mnk_hip.ptr(obs), mnk_hip.obs_code(obs),
+                         mnk_hip.ptr(self._err), self._flags() | (mnk_hip.STEP_AUTORESET if autoreset else 0),
+                         self._stream())
         if self.strict:
             self.check_errors()
 
-    def observe_into(self, obs=None, mask=None, flip_side=None, fix_empty_mask=False) -> None:
-        if self.num_envs and (obs is not None or mask is not None):
+    def step_random_into(self, rewards, dones, mask=None, obs=None, actions=None, *, seed: int, step: int, env_id0: int = 0,
+                         stream_id: int = mnk_hip.STREAM_MOVE, step_dev=None, autoreset: bool = True) -> None:
+        """One ply of uniform random play in ONE launch (``mnk_step_random``): every env draws its own legal move
+        from Philox(seed, env_id0 + i, step) -- the draw of ``sample_legal_into`` -- plays it, restarts if the game
+        ended (``autoreset``), and the legal mask / observation of the position that follows are written:
+        ``RandomPolicy.act -> env.step -> env.reset(nonzero(done)) -> env.observe()`` of the raw loop (SURVEY.md
+        Appendix A; policy.py:18-29, env:34-84).  ``actions`` (optional, int64 (N,)) receives the moves played."""
+        if self.num_envs:
+            mnk_hip.call("mnk_step_random", mnk_hip.ptr(self._planes), mnk_hip.ptr(self._meta), self.num_envs, self.m,
+                         self.n, self.k, seed, step, mnk_hip.ptr(step_dev), env_id0, stream_id, mnk_hip.ptr(actions),
+                         mnk_hip.ptr(rewards), mnk_hip.ptr(dones), mnk_hip.ptr(mask), mnk_hip.ptr(obs),
+                         mnk_hip.obs_code(obs), mnk_hip.STEP_AUTORESET if autoreset else 0, self._stream())
+
+    def observe_into(self, obs=None, mask=None, flip_side=None, fix_empty_mask=False, packed=None) -> None:
+        """``obs``: float32 / bfloat16 / uint8 (N, 2, m, n); ``mask``: bool (N, C); ``packed``: int64 (2, W, N), the same
+        view as packed planes (channel 0 first).  Any of them may be None."""
+        if self.num_envs and (obs is not None or mask is not None or packed is not None):
             mnk_hip.call("mnk_observe", mnk_hip.ptr(self._planes), mnk_hip.ptr(self._meta), self.num_envs, self.m,
-                         self.n, mnk_hip.ptr(flip_side), mnk_hip.ptr(obs), mnk_hip.ptr(mask),
-                         1 if fix_empty_mask else 0, self._stream())
+                         self.n, mnk_hip.ptr(flip_side), mnk_hip.ptr(obs), mnk_hip.obs_code(obs), mnk_hip.ptr(mask),
+                         1 if fix_empty_mask else 0, mnk_hip.ptr(packed), self._stream())
 
     def sample_legal_into(self, actions, seed: int, step: int, env_id0: int = 0,
                           stream_id: int = mnk_hip.STREAM_MOVE, step_dev=None) -> None:

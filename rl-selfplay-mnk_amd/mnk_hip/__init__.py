@@ -12,12 +12,13 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MNK_HIP_LIB: another build of the same library (A/B experiments with compile-time options); default: the in-tree build
 LIB_PATH = os.environ.get("MNK_HIP_LIB") or os.path.join(_HERE, "libmnk_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 MNK_OK = 0
 ERR_NONE, ERR_ACTION_RANGE, ERR_ILLEGAL_MOVE = 0, 1, 2
 STEP_STRICT, STEP_AUTORESET = 1, 2
 LOGITS_F32, LOGITS_BF16 = 0, 1
+OBS_F32, OBS_BF16, OBS_U8 = 0, 1, 2
 COMM_ID_BYTES = 128
 SP_NEED_OPP, SP_WAS_RESET = 1, 2
 STREAM_MOVE, STREAM_OPP, STREAM_SIDE, STREAM_SAMPLE = 0, 1, 2, 3
@@ -38,22 +39,23 @@ SIGNATURES = {
     "mnk_reset_all": [_vp, _vp, _i64, _i, _vp],
     "mnk_reset_idx": [_vp, _vp, _i64, _i, _vp, _i64, _vp, _vp],
     "mnk_reset_mask": [_vp, _vp, _i64, _i, _vp, _vp],
-    "mnk_step": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
-    "mnk_observe": [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp],
+    "mnk_step": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _vp, _u32, _vp],
+    "mnk_step_random": [_vp, _vp, _i64, _i, _i, _i, _u64, _u64, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _u32, _vp],
+    "mnk_observe": [_vp, _vp, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp],
     "mnk_pack_boards": [_vp, _vp, _i64, _i, _i, _vp],
     "mnk_unpack_boards": [_vp, _vp, _i64, _i, _i, _vp],
     "mnk_sample_legal": [_vp, _i64, _i, _i, _u64, _u64, _vp, _i64, _i, _vp, _vp],
     "mnk_sample_logits": [_vp, _i, _vp, _i64, _i, _u64, _u64, _vp, _i64, _i, _vp, _vp, _vp],
     "mnk_selfplay_pre": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _vp, _vp, _vp,
-                         _vp, _vp, _u32, _vp],
-    "mnk_selfplay_post": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                          _u32, _vp],
+                         _i, _vp, _vp, _u32, _vp],
+    "mnk_selfplay_post": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp,
+                          _vp, _u32, _vp],
     "mnk_selfplay_step_random": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _vp,
-                                 _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+                                 _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     "mnk_rollout_random": [_vp, _vp, _i64, _i, _i, _i, _i, _u64, _u64, _i64, _vp, _vp, _vp, _vp, _i, _vp],
     "mnk_replay_actions": [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp],
-    "mnk_unpack_records": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
-    "mnk_gather_obs": [_vp, _i64, _i64, _i, _i, _vp, _i64, _vp, _vp, _i, _vp, _vp],
+    "mnk_unpack_records": [_vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "mnk_gather_obs": [_vp, _i64, _i64, _i, _i, _vp, _i64, _vp, _i, _vp, _i, _vp, _vp],
     "mnk_gae": [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp],
     "mnk_jit_compile_rollout": [_i, _i, _i, _i, _i],
     "mnk_jit_last_error": [],
@@ -131,6 +133,23 @@ def call(name, *args):
             detail += ": " + (lib.mnk_comm_last_error() or b"").decode()
         raise MnkHipError(f"{name}: {detail}")
     return rc
+
+
+_OBS_DTYPES = {torch.float32: OBS_F32, torch.bfloat16: OBS_BF16, torch.uint8: OBS_U8}
+
+
+def obs_dtype_code(dtype) -> int:
+    """MNK_OBS_* code of a torch dtype an observation may be written in (float32 = the reference's; bfloat16 and
+    uint8 are the opt-in narrow forms: cells are exactly 0 / 1, so ``obs.float()`` is the same tensor)."""
+    try:
+        return _OBS_DTYPES[dtype]
+    except KeyError:
+        raise TypeError(f"observations can be written as float32, bfloat16 or uint8, not {dtype}") from None
+
+
+def obs_code(t) -> int:
+    """MNK_OBS_* code of an observation tensor (None -> F32: the pointer is NULL and the code is not looked at)"""
+    return OBS_F32 if t is None else obs_dtype_code(t.dtype)
 
 
 def state_words(m, n):

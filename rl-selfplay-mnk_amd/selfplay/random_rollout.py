@@ -263,14 +263,14 @@ def gather_records(rec: RolloutRecords, group=None) -> RolloutRecords:
     return RolloutRecords(planes=planes.contiguous(), meta=meta.contiguous())
 
 
-def unpack_records(rec: RolloutRecords, env) -> dict:
+def unpack_records(rec: RolloutRecords, env, obs_dtype=torch.float32) -> dict:
     """Packed records -> the field layout of the reference's ``RolloutBuffer``
     (``alg/rollout_buffer.py:14-44``): observations f32 [T,N,2,m,n] from the mover's point of view,
     action_masks bool [T,N,C], actions i64 [T,N], rewards f32 [T,N], dones bool [T,N].  One launch."""
     t, n = rec.meta.shape
     dev = rec.meta.device
     out = {
-        "observations": torch.empty((t, n, 2, env.m, env.n), dtype=torch.float32, device=dev),
+        "observations": torch.empty((t, n, 2, env.m, env.n), dtype=obs_dtype, device=dev),
         "action_masks": torch.empty((t, n, env.max_moves), dtype=torch.bool, device=dev),
         "actions": torch.empty((t, n), dtype=torch.long, device=dev),
         "rewards": torch.empty((t, n), dtype=torch.float32, device=dev),
@@ -278,7 +278,8 @@ def unpack_records(rec: RolloutRecords, env) -> dict:
     }
     if t and n:
         mnk_hip.call("mnk_unpack_records", mnk_hip.ptr(rec.planes), mnk_hip.ptr(rec.meta), n, t, env.m, env.n,
-                     mnk_hip.ptr(out["observations"]), mnk_hip.ptr(out["action_masks"]), mnk_hip.ptr(out["actions"]),
+                     mnk_hip.ptr(out["observations"]), mnk_hip.obs_code(out["observations"]),
+                     mnk_hip.ptr(out["action_masks"]), mnk_hip.ptr(out["actions"]),
                      mnk_hip.ptr(out["rewards"]), mnk_hip.ptr(out["dones"]), mnk_hip.stream_ptr(dev))
     return out
 

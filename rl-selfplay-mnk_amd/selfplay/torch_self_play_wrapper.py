@@ -18,6 +18,12 @@ those facts as bits and one step is
 with no host synchronisation; with the built-in ``RandomPolicy`` as opponent the
 three collapse into the single launch ``mnk_selfplay_step_random``.
 
+Every output of a step is caller-ownable: ``step(actions, out={...})`` writes the next observation, mask, rewards and
+terminated flags straight into the tensors it is given, and ``attach_sink(buffer)`` makes the wrapper take them from
+the rollout buffer itself -- row t+1 of ``observations`` / ``action_masks``, row t of ``rewards`` / ``dones`` -- so an
+agent-step reaches HBM once (the reference writes it, then ``RolloutBuffer.add`` reads and
+writes it again, alg/rollout_buffer.py:47-58).
+
 Differences a caller can observe, both deliberate:
   * the opponent policy is called ONCE per step on the full batch of N rows (rows that
     need no reply carry their current position and their answer is ignored), where the
@@ -55,6 +61,8 @@ class TorchSelfPlayWrapper:
         self._no_actions = torch.zeros(self.num_envs, dtype=torch.long, device=self._dev)
         self._ep_return = self._ep_length = self._ep_stats = None  # see track_episodes()
         self.step_dev = None  # optional device int64[1] added to step_count inside the kernels (graph replays)
+        self._sink = None     # see attach_sink()
+        self._truncated = torch.zeros(self.num_envs, dtype=torch.bool, device=self._dev)  # wrapper:66: always all-False
 
     def set_opponent(self, policy):  # reference wrapper:16-17
         self.opponent_policy = policy
@@ -73,6 +81,26 @@ class TorchSelfPlayWrapper:
         if t.numel() != self.num_envs:
             raise IndexError(f"shape mismatch: {t.numel()} sides for {self.num_envs} envs")
         return t
+
+    # ------------------------------------------------------------------ the rollout sink
+    def attach_sink(self, sink) -> None:
+        """Write every step's outputs straight into a rollout buffer (``alg.rollout_buffer.RolloutBuffer`` or
+        ``alg.packed_rollout_buffer.PackedRolloutBuffer``; anything with ``reset_outputs()`` / ``step_outputs()``).
+
+        With the buffer's write pointer at row t, ``step`` puts the next observation and mask into row t+1 of
+        ``observations`` / ``action_masks``, the rewards into row t of ``rewards`` and the terminated flags into row t of
+        ``dones``, and returns exactly those rows; ``reset`` puts the first observation into row t.  ``buffer.add``
+        recognises its own rows and copies nothing, so the reference's rollout loop (alg/ppo.py:93-108) runs unchanged
+        and the 7 ``copy_`` per step of alg/rollout_buffer.py:47-58 move ~1 MB instead of ~100 MB at 65 536 envs.  The
+        observation that follows the buffer's last row goes to a spill row of the buffer (``PPOAgent._last_obs`` across
+        ``learn`` calls); the buffer must keep its storage across ``reset()`` (the drop-in buffers do).
+        ``attach_sink(None)`` detaches."""
+        self._sink = sink
+
+    def _sink_outputs(self, is_reset: bool):
+        if self._sink is None:
+            return None
+        return self._sink.reset_outputs() if is_reset else self._sink.step_outputs()
 
     # ------------------------------------------------------------------ device-side episode statistics
     def track_episodes(self, on: bool = True) -> None:
@@ -121,8 +149,9 @@ class TorchSelfPlayWrapper:
                 dst.copy_(src)
 
     # ------------------------------------------------------------------ reference surface
-    def reset(self, seed=None, options=None):
-        """reference wrapper:19-30 (``seed`` is accepted and ignored there; here it re-keys Philox)"""
+    def reset(self, seed=None, options=None, out=None):
+        """reference wrapper:19-30 (``seed`` is accepted and ignored there; here it re-keys Philox).
+        ``out``: see ``step``."""
         if seed is not None:
             self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         forced = self._forced_sides
@@ -134,20 +163,26 @@ class TorchSelfPlayWrapper:
         if self._ep_stats is not None:
             self._ep_return.zero_()
             self._ep_length.fill_(-1)  # the reset itself is not a step of the first episode
-        obs, _, _, _, _ = self._advance(self._no_actions, forced)
+        obs, _, _, _, _ = self._advance(self._no_actions, forced, out if out is not None else self._sink_outputs(True))
         return obs, {}
 
-    def step(self, actions: torch.Tensor):
-        """reference wrapper:32-67"""
+    def step(self, actions: torch.Tensor, out=None):
+        """reference wrapper:32-67.
+
+        ``out``: optional dict of caller-owned, contiguous device tensors the step writes into instead of fresh ones --
+        ``"observation"`` (N, 2, m, n) float32 / bfloat16 / uint8, ``"action_mask"`` (N, C) bool, ``"rewards"`` (N,)
+        float32, ``"terminated"`` (N,) bool, ``"packed"`` int64 (2, W, N) (the observation as packed planes, extra).
+        Rows of a ``[T, N, ...]`` rollout buffer qualify; the returned tensors ARE the given ones.  Missing keys get fresh
+        tensors (``env.obs_dtype`` for the observation), as the reference returns."""
         a = torch.as_tensor(actions, device=self._dev).to(torch.long).reshape(-1).contiguous()
         if a.numel() != self.num_envs:
             raise IndexError(f"shape mismatch: {a.numel()} actions for {self.num_envs} envs")
-        return self._advance(a, self._forced_sides)
+        return self._advance(a, self._forced_sides, out if out is not None else self._sink_outputs(False))
 
     def get_agent_obs(self):
         """reference wrapper:99-115: the agent's stones in channel 0, mask[.,0] forced on full boards"""
         env = self.env
-        obs = torch.empty((self.num_envs, 2, env.m, env.n), dtype=torch.float32, device=self._dev)
+        obs = torch.empty((self.num_envs, 2, env.m, env.n), dtype=env.obs_dtype, device=self._dev)
         mask = torch.empty((self.num_envs, env.max_moves), dtype=torch.bool, device=self._dev)
         env.observe_into(obs, mask, flip_side=self.agent_side, fix_empty_mask=True)
         return {"observation": obs, "action_mask": mask}
@@ -158,24 +193,43 @@ class TorchSelfPlayWrapper:
         """The current canonical observation as packed planes, int64 [2, W, N] (channel 0 = the agent's
         stones): 32 B per env at 9x9 instead of the 729 B of observation + mask.  Feed it to
         ``alg.packed_rollout_buffer.PackedRolloutBuffer.add``; take it before the next ``step``."""
-        planes = self.env._planes
-        return torch.where((self.agent_side == 1).view(1, 1, -1), planes.flip(0), planes)
+        packed = torch.empty_like(self.env._planes)
+        self.env.observe_into(flip_side=self.agent_side, packed=packed)
+        return packed
 
     # ------------------------------------------------------------------ one fused step
-    def _advance(self, actions, forced):
+    def _out_tensor(self, out, key, shape, dtype):
+        """the caller's tensor for ``key`` (checked: it is handed to a kernel as a raw pointer) or a fresh one"""
+        t = out.get(key) if out else None
+        if t is None:
+            return torch.empty(shape, dtype=dtype, device=self._dev)
+        if dtype is None:  # the observation: any of the three dtypes the kernels write
+            mnk_hip.obs_dtype_code(t.dtype)
+        elif t.dtype != dtype:
+            raise TypeError(f"out[{key!r}] must be {dtype}, not {t.dtype}")
+        if tuple(t.shape) != tuple(shape) or not t.is_contiguous() or t.device != self._dev:
+            raise ValueError(f"out[{key!r}] must be a contiguous {tuple(shape)} tensor on {self._dev}, got "
+                             f"{tuple(t.shape)} (contiguous: {t.is_contiguous()}) on {t.device}")
+        return t
+
+    def _advance(self, actions, forced, out=None):
         env = self.env
         n = self.num_envs
         dev = self._dev
-        obs = torch.empty((n, 2, env.m, env.n), dtype=torch.float32, device=dev)
-        mask = torch.empty((n, env.max_moves), dtype=torch.bool, device=dev)
-        rewards = torch.empty(n, dtype=torch.float32, device=dev)
-        terminated = torch.empty(n, dtype=torch.bool, device=dev)
+        if out and "observation" in out and out["observation"] is not None:
+            obs = self._out_tensor(out, "observation", (n, 2, env.m, env.n), None)
+        else:
+            obs = torch.empty((n, 2, env.m, env.n), dtype=env.obs_dtype, device=dev)
+        mask = self._out_tensor(out, "action_mask", (n, env.max_moves), torch.bool)
+        rewards = self._out_tensor(out, "rewards", (n,), torch.float32)
+        terminated = self._out_tensor(out, "terminated", (n,), torch.bool)
+        packed = self._out_tensor(out, "packed", (2, env.words, n), torch.int64) if out and out.get("packed") is not None else None
         step = self.step_count
         if self.step_dev is None:
             self.step_count += 1
         opp = self.opponent_policy
         if n == 0:
-            return {"observation": obs, "action_mask": mask}, rewards, terminated, torch.zeros_like(terminated), {}
+            return {"observation": obs, "action_mask": mask}, rewards, terminated, self._truncated, {}
 
         if getattr(opp, "fused_uniform_random", False):
             # RandomPolicy opponent: the whole step is one launch
@@ -183,20 +237,22 @@ class TorchSelfPlayWrapper:
                          env.n, env.k, mnk_hip.ptr(actions), mnk_hip.ptr(self.pending_resets),
                          mnk_hip.ptr(self.agent_side), mnk_hip.ptr(forced), self.seed, step,
                          mnk_hip.ptr(self.step_dev), self.env_id0,
-                         mnk_hip.ptr(rewards), mnk_hip.ptr(terminated), mnk_hip.ptr(obs), mnk_hip.ptr(mask),
+                         mnk_hip.ptr(rewards), mnk_hip.ptr(terminated), mnk_hip.ptr(obs), mnk_hip.obs_code(obs),
+                         mnk_hip.ptr(mask), mnk_hip.ptr(packed),
                          mnk_hip.ptr(env._err), mnk_hip.ptr(self._ep_return), mnk_hip.ptr(self._ep_length),
                          mnk_hip.ptr(self._ep_stats), env._flags(), env._stream())
         else:
             if opp is None:
                 raise RuntimeError("TorchSelfPlayWrapper: set_opponent(policy) before reset()/step()")
-            opp_obs = torch.empty((n, 2, env.m, env.n), dtype=torch.float32, device=dev)
+            opp_obs = torch.empty((n, 2, env.m, env.n), dtype=env.obs_dtype, device=dev)
             opp_mask = torch.empty((n, env.max_moves), dtype=torch.bool, device=dev)
             mnk_hip.call("mnk_selfplay_pre", mnk_hip.ptr(env._planes), mnk_hip.ptr(env._meta), n, env.m, env.n,
                          env.k, mnk_hip.ptr(actions), mnk_hip.ptr(self.pending_resets), mnk_hip.ptr(self.agent_side),
                          mnk_hip.ptr(forced), self.seed, step, mnk_hip.ptr(self.step_dev), self.env_id0,
                          mnk_hip.ptr(rewards),
                          mnk_hip.ptr(terminated), mnk_hip.ptr(self._flags), mnk_hip.ptr(opp_obs),
-                         mnk_hip.ptr(opp_mask), mnk_hip.ptr(env._err), env._flags(), env._stream())
+                         mnk_hip.obs_code(opp_obs), mnk_hip.ptr(opp_mask), mnk_hip.ptr(env._err), env._flags(),
+                         env._stream())
             with torch.no_grad():  # wrapper:91-94: one positional argument, no `deterministic`
                 opp_actions = opp.act({"observation": opp_obs, "action_mask": opp_mask})
             opp_actions = torch.as_tensor(opp_actions, device=dev).to(torch.long).reshape(-1).contiguous()
@@ -205,8 +261,10 @@ class TorchSelfPlayWrapper:
             mnk_hip.call("mnk_selfplay_post", mnk_hip.ptr(env._planes), mnk_hip.ptr(env._meta), n, env.m, env.n,
                          env.k, mnk_hip.ptr(opp_actions), mnk_hip.ptr(self._flags), mnk_hip.ptr(self.agent_side),
                          mnk_hip.ptr(rewards), mnk_hip.ptr(terminated), mnk_hip.ptr(self.pending_resets),
-                         mnk_hip.ptr(obs), mnk_hip.ptr(mask), mnk_hip.ptr(env._err), mnk_hip.ptr(self._ep_return),
+                         mnk_hip.ptr(obs), mnk_hip.obs_code(obs), mnk_hip.ptr(mask), mnk_hip.ptr(packed),
+                         mnk_hip.ptr(env._err), mnk_hip.ptr(self._ep_return),
                          mnk_hip.ptr(self._ep_length), mnk_hip.ptr(self._ep_stats), env._flags(), env._stream())
         if env.strict:
             env.check_errors()
-        return {"observation": obs, "action_mask": mask}, rewards, terminated, torch.zeros_like(terminated), {}
+        # truncated (wrapper:66) is all-False by construction: one persistent tensor instead of a memset per step
+        return {"observation": obs, "action_mask": mask}, rewards, terminated, self._truncated, {}

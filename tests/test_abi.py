@@ -35,7 +35,8 @@ def test_header_declares_the_path():
     decl = declared_functions()
     for name in ("mnk_step", "mnk_observe", "mnk_reset_all", "mnk_reset_idx", "mnk_sample_legal",
                  "mnk_rollout_random", "mnk_replay_actions", "mnk_selfplay_pre", "mnk_selfplay_post", "mnk_sample_logits",
-                 "mnk_pack_boards", "mnk_unpack_boards", "mnk_unpack_records", "mnk_gather_obs", "mnk_gae"):
+                 "mnk_pack_boards", "mnk_unpack_boards", "mnk_unpack_records", "mnk_gather_obs", "mnk_gae",
+                 "mnk_step_random", "mnk_selfplay_step_random"):
         assert name in decl
 
 
@@ -62,7 +63,7 @@ def test_argument_errors_are_reported_not_crashed(lib):
     with pytest.raises(lib.MnkHipError):
         lib.call("mnk_reset_all", None, None, 16, 2, None)
     with pytest.raises(lib.MnkHipError):
-        lib.call("mnk_step", None, None, 16, 9, 9, 5, None, None, 16, None, None, None, None, None, 0, None)
+        lib.call("mnk_step", None, None, 16, 9, 9, 5, None, None, 16, None, None, None, None, 0, None, 0, None)
     with pytest.raises(lib.MnkHipError):
         lib.call("mnk_rollout_random", None, None, 16, 40, 40, 5, 4, 0, 0, 0, None, None, None, None, 0, None)
 

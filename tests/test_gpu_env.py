@@ -546,8 +546,8 @@ def test_step_with_autoreset_equals_step_reset_observe(hip, m, n, k, nenv):
     with pytest.raises(hip.lib.MnkHipError):  # subset steps have no autoreset form
         idx = torch.arange(4, device=DEV)
         hip.lib.call("mnk_step", hip.lib.ptr(env._planes), hip.lib.ptr(env._meta), nenv, m, n, k, hip.lib.ptr(acts[:4].contiguous()),
-                     hip.lib.ptr(idx), 4, hip.lib.ptr(rew), hip.lib.ptr(done), None, None, hip.lib.ptr(env._err),
-                     hip.lib.STEP_AUTORESET, env._stream())
+                     hip.lib.ptr(idx), 4, hip.lib.ptr(rew), hip.lib.ptr(done), None, None, hip.lib.OBS_F32,
+                     hip.lib.ptr(env._err), hip.lib.STEP_AUTORESET, env._stream())
 
 
 def test_long_launch_falls_back_to_64_bit_record_addresses(hip):
