@@ -8,9 +8,10 @@ env -- per ply: uniform legal move (RandomPolicy), place stone, 4-direction win 
 restart of finished games, packed record written to HBM.  ``value`` is env-steps (plies x envs)
 per second.  With --gpus N > 1 the env axis is sharded (65 536 envs per
 rank, global env ids key the RNG) and every chunk is all-gathered over RCCL on a side stream
-while the next chunk runs -- by default as chunk-start state + action log (1 B per env-step at
-9x9, rebuilt into full records on demand by mnk_replay_actions), with --gather records as the
-36 B packed records themselves.
+while the next chunk runs -- by default as the action log alone (7 bits per action at 9x9 = 0.875 B
+per env-step; every rank holds every shard's replay state, gathered once before the first chunk, and
+mnk_replay_actions rebuilds full records from state + log), with --gather actions+state as a
+self-contained message (chunk-start state + log), with --gather records as the 28 B packed records.
 
     python bench.py                       # 1 GPU, defaults finish in well under a minute
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -70,8 +71,12 @@ def parse():
                          "with a small conv policy as agent and an opponent pool (agent-steps/s, NN time dominates)")
     ap.add_argument("--backend", default="nccl", help="process-group backend; nccl = RCCL.  gloo is for rehearsing "
                     "the multi-rank path on a one-GPU box (all ranks then share device 0)")
-    ap.add_argument("--gather", choices=("actions", "records", "none"), default="actions",
-                    help="what ranks all-gather per chunk when --gpus > 1 (ignored on one GPU)")
+    ap.add_argument("--gather", choices=("actions", "actions+state", "records", "none"), default="actions",
+                    help="what ranks all-gather per chunk when --gpus > 1 (ignored on one GPU): the action log alone "
+                         "(receivers keep the replay state), the log with the chunk-start state, or the packed records")
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="if the C-ABI RCCL communicator (mnk_comm_*) cannot be created, run the same all-gather through "
+                         "torch.distributed instead of exiting non-zero")
     return ap.parse_args()
 
 
@@ -230,24 +235,206 @@ def api_path_graphed_rate(env, seed, plies_per_graph=64, replays=8, fused_reset=
     return replays * plies_per_graph * n / (time.perf_counter() - t0)
 
 
+def api_path_one_launch_rate(env, seed, plies_per_graph=64, replays=8):
+    """BASELINE config 2 with ONE launch per ply: mnk_step_random = the lane's own Philox draw + place stone + win scan
+    + reward / done + restart of a finished game + legal mask of the position that follows (policy.py:18-29 ->
+    env:55-84 -> env:34-44 -> env:46-53), ``plies_per_graph`` plies captured into a hipGraph and replayed.  Also
+    returns the per-ply time of the same graph on a 64-env batch: the floor one dependent launch costs here."""
+    dev = env._dev
+
+    def graphed(e):
+        n = e.num_envs
+        rew = torch.empty(n, dtype=torch.float32, device=dev)
+        done = torch.empty(n, dtype=torch.bool, device=dev)
+        mask = torch.empty((n, e.max_moves), dtype=torch.bool, device=dev)
+        step_dev = torch.full((1,), 1 << 22, dtype=torch.int64, device=dev)
+
+        def body():
+            for t in range(plies_per_graph):
+                e.step_random_into(rew, done, mask, seed=seed, step=t, step_dev=step_dev, autoreset=True)
+            step_dev.add_(plies_per_graph)
+
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            body()
+        graph.replay()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(replays):
+            graph.replay()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / (replays * plies_per_graph)
+
+    per_ply = graphed(env)
+    from env.torch_vector_mnk_env import TorchVectorMnkEnv
+
+    floor = graphed(TorchVectorMnkEnv(env.m, env.n, env.k, 64, device=str(dev)))
+    return env.num_envs / per_ply, per_ply * 1e6, floor * 1e6
+
+
+def write_ceiling_GBps(dev, nenv, chunk, rows, seconds=0.05):
+    """What the device sustains for the store pattern the rollout kernel is bound by: a write-only kernel that fills
+    rec[t][row][N] the way mnk_rollout_random does (mnk_probe_record_writes), timed with HIP events for ~50 ms."""
+    import mnk_hip
+
+    rec = torch.empty((chunk, rows, nenv), dtype=torch.int64, device=dev)
+    stream = mnk_hip.stream_ptr(dev)
+
+    def launch(k):
+        for _ in range(k):
+            mnk_hip.call("mnk_probe_record_writes", mnk_hip.ptr(rec), nenv, chunk, rows, stream)
+
+    launch(8)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch(4)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    per = e0.elapsed_time(e1) * 1e-3 / 4
+    k = max(4, int(seconds / max(per, 1e-6)))
+    e0.record()
+    launch(k)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return rec.numel() * 8 * k / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def gpu_identity(dev):
+    p = torch.cuda.get_device_properties(dev)
+    return {"name": p.name, "arch": getattr(p, "gcnArchName", None), "compute_units": p.multi_processor_count,
+            "clock_MHz": getattr(p, "clock_rate", 0) / 1e3 or None, "memory_GiB": round(p.total_memory / 2 ** 30, 1),
+            "hip": torch.version.hip}
+
+
+def selfplay_object(m, n, k, nenv, seed, dev, steps=64):
+    """BASELINE config 3's env side in the driver-run line: the TorchSelfPlayWrapper loop with the uniformly random
+    agent and the built-in random opponent, every step written straight into a RolloutBuffer (the fused sink).
+    Eager = the reference's loop shape from Python (alg/ppo.py:93-108: policy, step, buffer.add); graphed = the same
+    ``steps`` agent-steps as one hipGraph whose nodes write the buffer's rows (selfplay/graphed.py GraphedRollout)."""
+    from alg.rollout_buffer import RolloutBuffer
+    from env.torch_vector_mnk_env import TorchVectorMnkEnv
+    from selfplay.graphed import GraphedRollout
+    from selfplay.policy import RandomPolicy
+    from selfplay.torch_self_play_wrapper import TorchSelfPlayWrapper
+
+    c = m * n
+    out = {"what": f"{m}x{n}x{k}, {nenv} envs, TorchSelfPlayWrapper loop, uniformly random agent and opponent, "
+                   f"{steps} agent-steps per rollout written in place into a RolloutBuffer (observation f32 + mask + "
+                   "rewards + dones + actions + log-probs)"}
+    for sink in (True, False):
+        env = TorchVectorMnkEnv(m, n, k, nenv, device=str(dev))
+        wrap = TorchSelfPlayWrapper(env, seed=seed)
+        wrap.set_opponent(RandomPolicy(c, seed=seed + 1))
+        buf = RolloutBuffer(steps, nenv, (2, m, n), c, device=str(dev))
+        if sink:
+            wrap.attach_sink(buf)
+        agent = RandomPolicy(c, seed=seed + 2)
+        zeros = torch.zeros(nenv, device=dev)
+        obs, _ = wrap.reset()
+
+        def rollout():
+            nonlocal obs
+            buf.reset()
+            for _ in range(steps):
+                actions = agent.act(obs)
+                nxt, rew, term, trunc, _ = wrap.step(actions)
+                buf.add(obs["observation"], actions, rew, zeros, zeros, term | trunc, obs["action_mask"])
+                obs = nxt
+
+        rollout()
+        torch.cuda.synchronize(dev)
+        before = buf.copied_bytes
+        t0 = time.perf_counter()
+        for _ in range(3):
+            rollout()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / 3
+        key = "eager_sink" if sink else "eager_copying"
+        out[key + "_agent_steps_per_s"] = nenv * steps / dt
+        out[key + "_add_copied_bytes_per_agent_step"] = (buf.copied_bytes - before) / (3 * steps * nenv)
+        del buf, wrap, env
+    env = TorchVectorMnkEnv(m, n, k, nenv, device=str(dev))
+    wrap = TorchSelfPlayWrapper(env, seed=seed)
+    wrap.set_opponent(RandomPolicy(c, seed=seed + 1))
+    buf = RolloutBuffer(steps, nenv, (2, m, n), c, device=str(dev))
+    roll = GraphedRollout(wrap, buf, None, seed=seed + 2)
+    roll.run()
+    before = env._meta >> 1
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 5
+    for _ in range(reps):
+        roll.run()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / (reps * steps)
+    # algorithmic bytes of one agent-step written in place: state round trip, next observation f32 (8C) + mask (C),
+    # the mask read by the draw (C), action 8 + log-prob 4 + reward 4 + done 1 + side / pending / flags
+    words = env.words
+    alg = 2 * (16 * words + 4) + 8 * c + c + c + 8 + 4 + 4 + 1 + 8 + 1
+    out.update({
+        "graphed_agent_steps_per_s": nenv / (ms * 1e-3),
+        "graphed_env_side_us_per_agent_step": ms * 1e3,
+        "launches_per_agent_step": 2,
+        "alg_bytes_per_agent_step": alg,
+        "achieved_GBps": alg * nenv / (ms * 1e-3) / 1e9,
+        "frac_of_hbm_peak": alg * nenv / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "survey_B_agent_bytes": 2 * (16 * words + 4 + 8 * words + 4) + 17 * c + 15,
+    })
+    return out
+
+
+def with_action_log_rate(roll, chunk, steps):
+    """The kernel variant the multi-GPU runs use by default (--gather actions: records AND the action log written),
+    timed on one GPU like the headline (K launches, HIP events): the driver's N = 1 scaling point runs the
+    records-only variant (no exchange on one GPU), this is the per-GPU compute rate its N > 1 points start from."""
+    chunk = max(4, chunk - chunk % 4)
+    rec = roll.alloc(chunk, log_actions=True, with_state=False)
+    roll.step += (-roll.step) % 4  # a log starts on a multiple of four plies (the Philox block boundary)
+    for _ in range(512):  # as the headline's --settle: the device reaches its sustained clock after ~50 ms of load
+        roll.run(chunk, out=rec)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(steps):
+        roll.run(chunk, out=rec)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    n = roll.env.num_envs
+    return {"value": n * chunk / (ms * 1e-3), "unit": "env-steps/s", "avg_launch_us": ms * 1e3,
+            "kernel_variant": "records + action log " + {1: "(one byte per action)", 2: "(two bytes per action)",
+                                                         3: "(7-bit stream)"}[rec.fmt],
+            "log_bytes_per_env_step": rec.msg.numel() * 8 / (n * chunk)}
+
+
 def replay_rate(env, roll, chunk, reps=8):
     """Receiving side of the multi-GPU exchange: rebuild one shard's full records from its
     chunk-start state + action log (mnk_replay_actions); reported for transparency."""
-    from selfplay.random_rollout import GatheredLogs, replay_shard
+    from selfplay.random_rollout import GatheredLogs, gather_start_state, replay_shard
 
-    rec = roll.alloc(chunk, log_actions=True)
+    state = gather_start_state(env)  # one rank: a copy of the env state, advanced by the replays below
+    rec = roll.alloc(chunk, log_actions=True, with_state=False)  # the log alone, in the board's most compact format
     roll.run(chunk, out=rec)
-    logs = GatheredLogs.empty(1, env.words, env.num_envs, chunk, env.max_moves, env._dev)
+    logs = GatheredLogs.empty(1, 0, env.num_envs, chunk, env.max_moves, env._dev, fmt=rec.fmt, with_state=False)
     logs.msg.copy_(rec.msg.unsqueeze(0))
-    out = replay_shard(logs, 0, env.m, env.n, env.k)
+    out = replay_shard(logs, 0, env.m, env.n, env.k, state=state)
     assert torch.equal(out.planes, rec.planes) and torch.equal(out.meta, rec.meta), "replay != records"
-    scratch = (torch.empty_like(env._planes), torch.empty_like(env._meta))
+    assert torch.equal(state.planes[0], env._planes), "replay state != sender's state"
     err = torch.zeros(2, dtype=torch.int32, device=env._dev)
-    replay_shard(logs, 0, env.m, env.n, env.k, err=err, out=out, scratch=scratch)
+    # the timed replays re-play the same log from wherever the state stands: the same work per ply
+    replay_shard(logs, 0, env.m, env.n, env.k, err=err, out=out, state=state)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
-        replay_shard(logs, 0, env.m, env.n, env.k, err=err, out=out, scratch=scratch)
+        replay_shard(logs, 0, env.m, env.n, env.k, err=err, out=out, state=state)
     torch.cuda.synchronize()
     return reps * chunk * env.num_envs / (time.perf_counter() - t0)
 
@@ -412,7 +599,8 @@ def main():
     import mnk_hip
     from env.torch_vector_mnk_env import TorchVectorMnkEnv
     from selfplay.exchange import RecordExchange
-    from selfplay.random_rollout import GatheredLogs, RandomRollout, gather_action_logs
+    from selfplay.random_rollout import (ACT_BITS7, GatheredLogs, RandomRollout, action_log_format, gather_action_logs,
+                                         gather_start_state)
 
     mnk_hip.load()
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
@@ -432,29 +620,41 @@ def main():
     env.reset()
     roll = RandomRollout(env, seed=args.seed, env_id0=rank * nenv)
     mode = args.gather if world > 1 else "none"
-    if mode == "actions":  # a log word holds plies 4q..4q+3: chunks (and so the warm-up) end on multiples of 4
+    logging = mode in ("actions", "actions+state")
+    if logging:  # a group of the log holds plies 4q..4q+3: chunks (and so the warm-up) end on multiples of 4
         chunk = args.chunk = max(4, chunk - chunk % 4)
-    bufs = [roll.alloc(chunk, log_actions=(mode == "actions")) for _ in range(2)]
-    gathered = side = exchange = None
+    bufs = [roll.alloc(chunk, log_actions=logging, with_state=(mode == "actions+state")) for _ in range(2)]
+    gathered = side = exchange = start_state = None
     if mode != "none":
         side = torch.cuda.Stream(dev)
         if args.backend == "nccl":  # the collective goes through the C ABI (mnk_allgather_records), RCCL over xGMI
+            failure = None
             try:
                 exchange = RecordExchange.from_process_group()
-            except Exception as e:  # noqa: BLE001 -- the same all-gather through torch.distributed's RCCL instead
-                print(f"[bench rank {rank}] C-ABI communicator unavailable ({e}); using torch.distributed", file=sys.stderr)
+            except Exception as e:  # noqa: BLE001
+                failure = e
                 exchange = None
             # every rank must take the same path
             ok = torch.tensor([1 if exchange is not None else 0], device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0 and exchange is not None:
-                exchange.close()
-                exchange = None
+            if int(ok.item()) == 0:
+                if exchange is not None:
+                    exchange.close()
+                    exchange = None
+                if not args.allow_fallback:  # a run that quietly measures another transport is worse than no run
+                    print(f"[bench rank {rank}] the C-ABI RCCL communicator (mnk_comm_init) could not be created on every "
+                          f"rank ({failure}); --allow-fallback runs the all-gather through torch.distributed instead",
+                          file=sys.stderr)
+                    dist.destroy_process_group()
+                    sys.exit(3)
+                print(f"[bench rank {rank}] C-ABI communicator unavailable ({failure}); using torch.distributed",
+                      file=sys.stderr)
         if mode == "records":
             gathered = [(torch.empty((world,) + tuple(b.planes.shape), dtype=torch.int64, device=dev),
                          torch.empty((world,) + tuple(b.meta.shape), dtype=torch.int32, device=dev)) for b in bufs]
         else:
-            gathered = [GatheredLogs.empty(world, env.words, nenv, chunk, env.max_moves, dev) for _ in bufs]
+            gathered = [GatheredLogs.empty(world, env.words, nenv, chunk, env.max_moves, dev, fmt=bufs[0].fmt,
+                                           with_state=(mode == "actions+state")) for _ in bufs]
     main_stream = torch.cuda.current_stream(dev)
     gather_done = [None, None]
     kernel_events = []  # (start, end) HIP events around every rollout launch of the timed region
@@ -492,7 +692,7 @@ def main():
                     if timing[0]:
                         gs = torch.cuda.Event(enable_timing=True)
                         gs.record(side)
-                    if mode == "actions":
+                    if logging:
                         gather_action_logs(out, out=gathered[slot], exchange=exchange, stream=side)
                     else:
                         gp, gm = gathered[slot]
@@ -518,6 +718,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if mode == "actions":
+        # the log travels alone: every rank takes every shard's start state once (36 B per env), outside the timed
+        # region, and from then on advances it by replaying the logs (replay_shard(..., state=start_state))
+        start_state = gather_start_state(env, exchange=exchange, stream=main_stream)
+        torch.cuda.synchronize(dev)
     run_steps(args.settle * chunk)
     barrier()
     run_steps(args.warmup * chunk)
@@ -603,6 +808,13 @@ def main():
                                                    if mode != "none" else ""),
             "envs_per_gpu": nenv, "chunk": chunk, "board": args.board, "seed": args.seed, "gather": mode,
         },
+        # what exactly ran (the driver compares its N = 1 point with the one-GPU line): the exchange mode, the kernel
+        # variant that mode implies, and the transport of the collective
+        "gather": mode,
+        "kernel_variant": "records + action log " + {1: "(one byte per action)", 2: "(two bytes per action)",
+                                                     3: "(7-bit stream)"}[bufs[0].fmt] if logging
+                          else "records only (no action log)",
+        "transport": None,
         "roofline": {
             "bound": "hbm",
             "achieved": achieved,
@@ -622,7 +834,7 @@ def main():
         },
     }
     if mode != "none":
-        if mode == "actions":
+        if logging:
             msg_bytes = bufs[0].msg.numel() * 8
         else:
             msg_bytes = bufs[0].planes.numel() * 8 + bufs[0].meta.numel() * 4
@@ -634,10 +846,14 @@ def main():
         compute_ms = world * nenv * plies / compute_only * 1e3 / args.steps
         exposed_ms = max(0.0, step_ms - compute_ms)
         out["exchange"] = {
-            "what": {"actions": "chunk-start planes | action log (4 plies per word) | chunk-start meta",
+            "what": {"actions": "the action log alone (7-bit stream up to 128 cells, else 1-2 bytes per action); every rank "
+                                "holds every shard's replay state, gathered once before the first chunk",
+                     "actions+state": "chunk-start planes | action log | chunk-start meta (a self-contained message)",
                      "records": "packed records (rows + meta word per ply)"}[mode],
+            "start_state_bytes_per_rank": start_state.msg.shape[1] * 8 if start_state is not None else 0,
             "transport": "mnk_allgather_records (C ABI, RCCL)" if exchange is not None
-                         else f"torch.distributed {args.backend}",
+                         else f"torch.distributed {args.backend}" + (" (FALLBACK: the C-ABI communicator failed)"
+                                                                     if args.backend == "nccl" else ""),
             "bytes_per_rank_per_chunk": msg_bytes,
             "bytes_per_env_step": msg_bytes / (nenv * chunk),
             "allgather_ms": mean_ms,                      # slowest rank's mean, HIP events on the side stream
@@ -650,15 +866,32 @@ def main():
             "exposed_ms_per_chunk": exposed_ms,           # step time minus the compute-only step time
             "overlap_fraction": max(0.0, 1.0 - exposed_ms / mean_ms) if mean_ms else None,
         }
+    if mode != "none":
+        out["transport"] = out["exchange"]["transport"]
     if rank == 0:
         stats = roll.stats.tolist()
         out["rollout_stats"] = {"episodes": stats[0], "mean_plies": stats[4] / max(stats[0], 1),
                                 "draw_rate": stats[3] / max(stats[0], 1)}
+        out["gpu"] = gpu_identity(dev)
         if world == 1 and not args.no_api_path:
+            out["roofline"]["measured_write_ceiling_GBps"] = write_ceiling_GBps(dev, nenv, chunk, rows)
+            out["roofline"]["frac_of_measured_write_ceiling"] = achieved / out["roofline"]["measured_write_ceiling_GBps"]
             out["api_path_env_steps_per_s"] = api_path_rate(env, args.seed)
             out["api_path_graphed_env_steps_per_s"] = api_path_graphed_rate(env, args.seed)
             out["api_path_graphed_fused_reset_env_steps_per_s"] = api_path_graphed_rate(env, args.seed, fused_reset=True)
+            one, per_ply_us, floor_us = api_path_one_launch_rate(env, args.seed)
+            out["api_path_graphed_one_launch_env_steps_per_s"] = one
+            out["api_path_one_launch"] = {
+                "us_per_ply": per_ply_us, "launch_floor_us": floor_us,
+                "what": "mnk_step_random: draw + step + win scan + reset + legal mask in one launch per ply, 64 plies per "
+                        "hipGraph; launch_floor_us = the same graph on 64 envs (what one dependent launch costs)",
+                # SURVEY.md section 8d's B_step without the action read: state in, mover's plane + meta out, reward, done, mask
+                "alg_bytes_per_env_step": state_bytes(words) + 8 * words + 4 + 5 + m * n,
+                "frac_of_hbm_peak": (state_bytes(words) + 8 * words + 4 + 5 + m * n) * one / 1e9 / HBM_PEAK_GBS,
+            }
             out["replay_env_steps_per_s"] = replay_rate(env, roll, chunk)
+            out["with_action_log"] = with_action_log_rate(roll, chunk, args.steps)
+            out["selfplay"] = selfplay_object(m, n, k, nenv, args.seed, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(env, args.cpu_seconds, args.cpu_threads)
         else:

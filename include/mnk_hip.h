@@ -82,6 +82,13 @@ extern "C" {
 #define MNK_LOGITS_F32 0
 #define MNK_LOGITS_BF16 1 /* what the reference's networks emit under alg/ppo.py:194 autocast on Ampere+ (utils/hardware.py:38-41) */
 
+/* format of the action log (`act_bytes` of mnk_rollout_random / mnk_replay_actions / mnk_jit_compile_rollout) */
+#define MNK_ACT_U8 1    /* one byte per action, boards of at most 256 cells: u32[ceil(T/4)][N] */
+#define MNK_ACT_U16 2   /* 16 bits per action: u64[ceil(T/4)][N] */
+#define MNK_ACT_BITS7 3 /* 7 bits per action, boards of at most 128 cells: a bit stream, ply p at bit 7p, in u32 words
+                         * [mnk_action_log_words(MNK_ACT_BITS7, T)][N] -- 0.875 B per env-step, what the ranks of
+                         * BASELINE.json configs 2-4 (9x9: 81 cells) put on xGMI */
+
 /* bytes of the opaque communicator id exchanged between ranks (= NCCL_UNIQUE_ID_BYTES) */
 #define MNK_COMM_ID_BYTES 128
 
@@ -252,13 +259,18 @@ const char* mnk_jit_last_error(void);
 /* The multi-GPU exchange format.  A shard's rollout is a pure function of its chunk-start state and
  * its actions, so the action log, optionally written by mnk_rollout_random, is what ranks all-gather
  * (1-2 B per env-step instead of the 28 B packed record or the reference's 750 B RolloutBuffer row).
- * Layout: four plies per word, act_log u32[ceil(T/4)][N] (act_bytes 1: one byte per action, boards with
- * <= 256 cells) or u64[ceil(T/4)][N] (act_bytes 2: 16 bits per action); the action of ply 4q+j is field j
- * (little-endian) of word [q][i]; fields past T are 0.  With a log, step0 must be a multiple of 4 (every
- * chunk but the last a multiple of 4 plies).
+ * Layout: four plies per word, act_log u32[ceil(T/4)][N] (act_bytes MNK_ACT_U8: one byte per action, boards with
+ * <= 256 cells) or u64[ceil(T/4)][N] (MNK_ACT_U16: 16 bits per action); the action of ply 4q+j is field j
+ * (little-endian) of word [q][i]; fields past T are 0.  MNK_ACT_BITS7 (boards with <= 128 cells): 7 bits per action
+ * as one bit stream per env, see above.  With a log, step0 must be a multiple of 4 (every chunk but the last a
+ * multiple of 4 plies).  A receiver that replays every chunk of a shard in order holds that shard's chunk-start state
+ * itself, so after the first chunk the log alone is the message (selfplay/random_rollout.py).
  * mnk_replay_actions re-plays a log from `planes`/`meta` (updated in place, like the rollout) and
  * rebuilds rec_planes / rec_meta bit-identical to what the sender recorded (both may be NULL to only
  * advance the state).  An action >= m*n in the log is reported through err. */
+/* 32-bit words per env of a T-ply log in format `act_bytes` (0 for an unknown format): U8 ceil(T/4), U16 2 ceil(T/4),
+ * BITS7 ceil(7 ceil(T/4) / 8) */
+int mnk_action_log_words(int act_bytes, int T);
 int mnk_replay_actions(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, int T,
                        const void* act_log, int act_bytes, uint64_t* rec_planes, uint32_t* rec_meta,
                        int32_t* err, void* stream);
@@ -300,6 +312,11 @@ int mnk_allgather_records(void* comm, const void* send, void* recv, int64_t byte
 const char* mnk_comm_last_error(void);
 /* NCCL_VERSION_CODE of the resolved library, 0 when none could be resolved */
 int mnk_comm_version(void);
+
+/* Measurement aid (bench.py: `roofline.measured_write_ceiling_GBps`): fills rec u64[T][rows][N] with a write-only
+ * kernel that has the store pattern of the rollout records and no game logic -- the write rate the device sustains
+ * for the access pattern mnk_rollout_random is bound by. */
+int mnk_probe_record_writes(uint64_t* rec, int64_t N, int T, int rows, void* stream);
 
 #ifdef __cplusplus
 }

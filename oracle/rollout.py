@@ -105,3 +105,50 @@ def gae(rewards, values, dones, last_values, gamma=0.99, lam=0.95):
         run = delta + gl * nonterm[t] * run
         adv[t] = run
     return adv, adv + values
+
+
+# ---- action-log formats of the multi-GPU exchange (include/mnk_hip.h MNK_ACT_*), restated in numpy
+ACT_U8, ACT_U16, ACT_BITS7 = 1, 2, 3
+
+
+def encode_action_log(actions, fmt: int) -> np.ndarray:
+    """actions int [T, N] -> the packed log ``mnk_rollout_random`` writes for them:
+    ACT_U8    uint32 [ceil(T/4), N]   action of ply 4q+j in byte j of word q
+    ACT_U16   uint64 [ceil(T/4), N]   ... in 16-bit field j
+    ACT_BITS7 uint32 [ceil(7 ceil(T/4) / 8), N]   a bit stream per env, action of ply p at bits [7p, 7p+7)
+    Plies past T count as action 0."""
+    a = np.asarray(actions, dtype=np.uint64)
+    t, n = a.shape
+    q = (t + 3) // 4
+    a = np.concatenate([a, np.zeros((4 * q - t, n), dtype=np.uint64)])
+    if fmt in (ACT_U8, ACT_U16):
+        bits = 8 if fmt == ACT_U8 else 16
+        quads = a.reshape(q, 4, n)
+        word = quads[:, 0] | quads[:, 1] << np.uint64(bits) | quads[:, 2] << np.uint64(2 * bits) | quads[:, 3] << np.uint64(3 * bits)
+        return word.astype(np.uint32) if fmt == ACT_U8 else word
+    assert fmt == ACT_BITS7 and (a < 128).all()
+    words = (7 * q + 7) // 8
+    out = np.zeros((words + 1, n), dtype=np.uint64)
+    for p in range(4 * q):
+        w, sh = divmod(7 * p, 32)
+        v = a[p] << np.uint64(sh)
+        out[w] |= v & np.uint64(0xFFFFFFFF)
+        out[w + 1] |= v >> np.uint64(32)
+    assert not out[words].any()
+    return out[:words].astype(np.uint32)
+
+
+def decode_action_log(log, steps: int, fmt: int) -> np.ndarray:
+    """inverse of ``encode_action_log``: int64 actions [steps, N]"""
+    log = np.asarray(log)
+    if fmt in (ACT_U8, ACT_U16):
+        bits = 8 if fmt == ACT_U8 else 16
+        w = log.astype(np.uint64)
+        fields = [(w >> np.uint64(bits * j)) & np.uint64((1 << bits) - 1) for j in range(4)]
+        return np.stack(fields, axis=1).reshape(-1, log.shape[1])[:steps].astype(np.int64)
+    w = np.concatenate([log.astype(np.uint64), np.zeros((1, log.shape[1]), dtype=np.uint64)])
+    out = np.zeros((steps, log.shape[1]), dtype=np.int64)
+    for p in range(steps):
+        i, sh = divmod(7 * p, 32)
+        out[p] = (((w[i] | (w[i + 1] << np.uint64(32))) >> np.uint64(sh)) & np.uint64(0x7F)).astype(np.int64)
+    return out

@@ -35,8 +35,9 @@ class PackedRolloutBuffer:
 
     def reset(self):
         t, n, dev = self.n_steps, self.num_envs, self.device
-        if getattr(self, "planes", None) is not None:  # keep the storage: rows may be bound to the fused step
-            for f in (self._plane_store, self.actions, self.log_probs, self.rewards, self.values, self.returns,
+        if getattr(self, "planes", None) is not None:  # keep the storage: rows may be bound to the fused step; the spill
+            # row is left alone -- it carries the observation the next rollout starts from
+            for f in (self.planes, self.actions, self.log_probs, self.rewards, self.values, self.returns,
                       self.advantages, self.dones):
                 f.zero_()
             self.ptr = 0

@@ -109,6 +109,15 @@ inline int mnk_block_threads() {
     else MNK_CASE(16, 0, 0, __VA_ARGS__)                                              \
   } while (0)
 #define MNK_K(name) HIP_KERNEL_NAME(name<NW, CN, CK>)
+// the variants a board of at most 128 cells can have (the 7-bit action stream): 9x9x5, 3x3x3, generic up to 8 words
+#define MNK_DISPATCH_SMALL(g, ...)                                                    \
+  do {                                                                                \
+    if ((g).n == 9 && (g).k == 5 && (g).NW == 3) MNK_CASE(3, 9, 5, __VA_ARGS__)       \
+    else if ((g).n == 3 && (g).k == 3 && (g).NW == 1) MNK_CASE(1, 3, 3, __VA_ARGS__)  \
+    else if ((g).NW <= 2) MNK_CASE(2, 0, 0, __VA_ARGS__)                              \
+    else if ((g).NW <= 4) MNK_CASE(4, 0, 0, __VA_ARGS__)                              \
+    else MNK_CASE(8, 0, 0, __VA_ARGS__)                                               \
+  } while (0)
 
 
 // may the one-lane rollout address its record stores with 32-bit lane offsets (SADDR form)?  Only while a wave is
@@ -117,6 +126,11 @@ inline bool mnk_rollout_saddr_ok(const MnkGeom& g, int64_t N, int T) {
   const char* v = getenv("MNK_ROLLOUT_SADDR");  // "0" switches the form off (A/B timing; read per call)
   if (v && atoi(v) == 0) return false;
   return N <= 65536 && ((int64_t)T * g.NW + 1) * N * 8 < (1ll << 32);
+}
+
+// is `act` a log format this board can use?  (0 = no log)
+inline bool mnk_act_format_ok(int act, int C) {
+  return act == 0 || act == MNK_ACT_U16 || (act == MNK_ACT_U8 && C <= 256) || (act == MNK_ACT_BITS7 && C <= 128);
 }
 
 // one-lane rollout variants that write the action log (mnk_rollout_log.hip); act_bytes is 1 or 2

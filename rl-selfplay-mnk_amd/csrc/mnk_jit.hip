@@ -109,7 +109,7 @@ int64_t mnk_jit_compile_rollout(int m, int n, int k, int record, int act_bytes) 
   MnkGeom g;
   const int rc = mnk_check_geom(m, n, k, &g);
   if (rc != MNK_OK) return rc;
-  if (act_bytes < 0 || act_bytes > 2) return MNK_EINVAL;
+  if (!mnk_act_format_ok(act_bytes, g.C)) return MNK_EINVAL;
   std::vector<char> code;
   if (!compile(g, record != 0, act_bytes, record != 0, code)) return MNK_ELAUNCH;  // the form a 65 536-env launch uses
   return (int64_t)code.size();

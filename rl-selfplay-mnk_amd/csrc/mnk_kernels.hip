@@ -527,8 +527,33 @@ k_gae(const float* rewards, const float* values, const uint8_t* dones, const flo
   }
 }
 
+// ------------------------------------------------------------------ measurement aid
+// A write-only kernel with the store pattern of the rollout records (rec[t][row][N] u64: one wave = 64 consecutive
+// envs walking t, 512-byte pieces at stride 8N) and no game logic: what the device sustains for this access pattern.
+// bench.py times it next to the roofline (`roofline.measured_write_ceiling_GBps`); tools/exp_write_pattern.hip
+// compares it with other layouts.
+__global__ void __launch_bounds__(64) k_probe_record_writes(uint64_t* rec, int64_t N, int T, int rows, uint64_t seed) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= N) return;
+  uint64_t v = seed + (uint64_t)i;
+  uint64_t* p = rec + i;
+  for (int t = 0; t < T; ++t)
+    for (int r = 0; r < rows; ++r) {
+      __builtin_nontemporal_store(v + (uint64_t)r, p);
+      p += N;
+    }
+}
+
 // ================================================================== C ABI
 extern "C" {
+
+int mnk_probe_record_writes(uint64_t* rec, int64_t N, int T, int rows, void* stream) {
+  if (!rec || N < 0 || T < 0 || rows < 1) return MNK_EINVAL;
+  if (N == 0 || T == 0) return MNK_OK;
+  hipLaunchKernelGGL(k_probe_record_writes, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, rec, N, T,
+                     rows, 0x9E3779B97F4A7C15ull);
+  return mnk_launch_status("probe_record_writes");
+}
 
 int mnk_abi_version(void) { return MNK_ABI_VERSION; }
 

@@ -12,6 +12,8 @@
 // plies per log word, unrolled with compile-time field positions (round 1 looped ply by ply with a run-time field
 // and a branch per ply: 1.2e11 env-steps/s, slower than producing the log); the next word is fetched while the
 // current four plies are played.
+// ACTB = 3 (MNK_ACT_BITS7): the log is a stream of 7-bit actions; the reader mirrors the writer of mnk_rollout_lane.h --
+// a 64-bit accumulator whose fill level is wave-uniform, one u32 word fetched (ahead) whenever fewer than 28 bits remain.
 template <int NW, int CN, int CK, bool RECORD, int ACTB>
 __global__ void __launch_bounds__(64)
 k_replay_actions(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, const void* act_log,
@@ -20,6 +22,53 @@ k_replay_actions(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, 
   if (i >= N) return;
   RolloutLane<NW, CN, CK, RECORD> L(g, N, i, rec_planes, rec_meta, nullptr);
   L.load(planes, meta, i);
+  if constexpr (ACTB == 3) {
+    bool bad7 = false;
+    auto play7 = [&](uint32_t a) {
+      if (a >= (uint32_t)g.C) { bad7 = true; a = 0; }
+      L.ply_action((int)a);
+    };
+    const int quads = (T + 3) >> 2, nwords = (7 * quads + 7) >> 3;
+    const uint32_t* src = (const uint32_t*)act_log + i;
+    uint32_t ahead = nwords ? src[0] : 0u;
+    int w = 1;
+    uint32_t cur = 0, have = 0;  // bits left over from the last word (low-aligned) and their number: 0, 4, ..., 28 (uniform)
+    auto take_word = [&]() -> uint32_t {
+      const uint32_t word = ahead;
+      ahead = src[(int64_t)(w < nwords ? w : nwords - 1) * N];
+      ++w;
+      return word;
+    };
+    auto next_quad = [&]() -> uint32_t {  // 32-bit arithmetic only; seven words per eight quads
+      uint32_t q;
+      if (have == 28u) {
+        q = cur;
+        cur = 0u;
+        have = 0u;
+      } else {
+        const uint32_t word = take_word();
+        q = (cur | (word << have)) & 0x0FFFFFFFu;  // have == 0: cur == 0
+        cur = word >> (28u - have);
+        have += 4u;
+      }
+      return q;
+    };
+    int t = 0;
+    for (; t + 4 <= T; t += 4) {
+      const uint32_t q = next_quad();
+      play7(q & 0x7Fu);
+      play7((q >> 7) & 0x7Fu);
+      play7((q >> 14) & 0x7Fu);
+      play7((q >> 21) & 0x7Fu);
+    }
+    if (t < T) {
+      uint32_t q = next_quad();
+      for (; t < T; ++t, q >>= 7) play7(q & 0x7Fu);
+    }
+    if (bad7) mnk_report(err, MNK_ERR_ACTION_RANGE, i);
+    L.store(planes, meta, i);
+    return;
+  }
   constexpr uint32_t FIELD = ACTB == 1 ? 0xFFu : 0xFFFFu;
   auto fetch = [&](int q) -> uint64_t {
     if (ACTB == 1) return (uint64_t)((const uint32_t*)act_log)[(int64_t)q * N + i];
@@ -56,7 +105,7 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   int rc = mnk_check_geom(m, n, k, &g);
   if (rc != MNK_OK) return rc;
   if (!planes || !meta || N < 0 || T < 0 || T > 65535 || (!rec_planes != !rec_meta)) return MNK_EINVAL;
-  if (act_log && !(act_bytes == 2 || (act_bytes == 1 && g.C <= 256))) return MNK_EINVAL;
+  if (act_log && (act_bytes == 0 || !mnk_act_format_ok(act_bytes, g.C))) return MNK_EINVAL;
   if (act_log && (step0 & 3)) return MNK_EINVAL;  // log words hold plies 4q..4q+3 of the Philox step counter
   if (!act_log) act_bytes = 0;
   if (N == 0 || T == 0) return MNK_OK;
@@ -71,7 +120,8 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
                          (g.n == 13 && g.k == 5 && g.NW == 6) || (g.n == 15 && g.k == 5 && g.NW == 8) ||
                          (g.n == 19 && g.k == 5 && g.NW == 12);
   const bool w_fits = ((int64_t)T * g.NW + 1) * N * 8 < (1ll << 32);  // the two-lane forms' record stores use 32-bit byte offsets
-  const bool use_pair = pair_geom && w_fits &&
+  // (the 7-bit action stream exists in the one-lane form only: a launch that writes one never takes a two-lane form)
+  const bool use_pair = pair_geom && w_fits && act_bytes != MNK_ACT_BITS7 &&
                         (pair_override >= 0 ? pair_override != 0 : N <= 32768);
   const bool rec = rec_planes && rec_meta;
   // MNK_ROLLOUT_FORM=lane|pair|ws2|ws4 forces a kernel form (read per call: A/B timing, parity tests of every form)
@@ -79,7 +129,7 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   int ws = 0;
   if (form && !strcmp(form, "ws2")) ws = 2;
   if (form && !strcmp(form, "ws4")) ws = 4;
-  if (ws && mnk_rollout_ws_supported(g, act_bytes)) {
+  if (ws && act_bytes != MNK_ACT_BITS7 && mnk_rollout_ws_supported(g, act_bytes)) {
     mnk_launch_rollout_ws(g, ws, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,
                           rec ? rec_meta : nullptr, stats, act_log, act_bytes, stream);
     return mnk_launch_status("rollout_random_ws");
@@ -101,7 +151,8 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   // directions); MNK_ROLLOUT_FORM=pair|pairw forces one (pairw at any batch size)
   const bool force_w = form && !strcmp(form, "pairw");
   const bool force_d = form && !strcmp(form, "pair");
-  if (mnk_rollout_pairw_supported(g) && w_fits && (force_w || (use_pair && !force_d && g.n >= 13))) {
+  if (mnk_rollout_pairw_supported(g) && w_fits && act_bytes != MNK_ACT_BITS7 &&
+      (force_w || (use_pair && !force_d && g.n >= 13))) {
     mnk_launch_rollout_pairw(g, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,
                              rec ? rec_meta : nullptr, stats, act_log, act_bytes, stream);
     return mnk_launch_status("rollout_random_pairw");
@@ -143,13 +194,22 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   return mnk_launch_status("rollout_random");
 }
 
+int mnk_action_log_words(int act_bytes, int T) {
+  if (T < 0) return 0;
+  const int q = (T + 3) >> 2;
+  if (act_bytes == MNK_ACT_U8) return q;
+  if (act_bytes == MNK_ACT_U16) return 2 * q;
+  if (act_bytes == MNK_ACT_BITS7) return (7 * q + 7) >> 3;
+  return 0;
+}
+
 int mnk_replay_actions(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, int T, const void* act_log,
                        int act_bytes, uint64_t* rec_planes, uint32_t* rec_meta, int32_t* err, void* stream) {
   MnkGeom g;
   int rc = mnk_check_geom(m, n, k, &g);
   if (rc != MNK_OK) return rc;
   if (!planes || !meta || !act_log || N < 0 || T < 0 || (!rec_planes != !rec_meta)) return MNK_EINVAL;
-  if (!(act_bytes == 2 || (act_bytes == 1 && g.C <= 256))) return MNK_EINVAL;
+  if (act_bytes == 0 || !mnk_act_format_ok(act_bytes, g.C)) return MNK_EINVAL;
   if (N == 0 || T == 0) return MNK_OK;
   const int B = 64;
   const dim3 grid((unsigned)((N + B - 1) / B));
@@ -158,7 +218,15 @@ int mnk_replay_actions(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
                                      (hipStream_t)stream, g, planes, meta, N, T, act_log, REC ? rec_planes : nullptr, \
                                      REC ? rec_meta : nullptr, err))
   const bool rec = rec_planes && rec_meta;
-  if (rec && act_bytes == 1) MNK_REPLAY(true, 1);
+  if (act_bytes == MNK_ACT_BITS7) {
+#define MNK_REPLAY7(REC)                                                                                               \
+  MNK_DISPATCH_SMALL(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_replay_actions<NW, CN, CK, REC, 3>), grid, dim3(B), 0,    \
+                                           (hipStream_t)stream, g, planes, meta, N, T, act_log,                        \
+                                           REC ? rec_planes : nullptr, REC ? rec_meta : nullptr, err))
+    if (rec) MNK_REPLAY7(true);
+    else MNK_REPLAY7(false);
+#undef MNK_REPLAY7
+  } else if (rec && act_bytes == 1) MNK_REPLAY(true, 1);
   else if (rec) MNK_REPLAY(true, 2);
   else if (act_bytes == 1) MNK_REPLAY(false, 1);
   else MNK_REPLAY(false, 2);

@@ -19,6 +19,13 @@
 // field j of word [q][i] -- so a wave writes 256 / 512 contiguous bytes per store and the field position is a
 // compile-time constant in the unrolled loop: +7 % kernel time.  (One byte store per lane per ply, and a packed
 // word with a run-time field index, were both measured at +20 %.)
+// ACT = 3 (MNK_ACT_BITS7, boards of at most 128 cells): the log is a stream of 7-bit actions, ply p at bit 7p, in u32
+// words [ceil(7 * ceil(T/4) / 8)][N] -- 0.875 B per env-step on the wire.  Four plies still gather in `quad` at
+// compile-time positions (28 bits, one 32-bit register); the quads then go through a 32-bit accumulator whose fill level
+// is wave-uniform (every lane is at the same ply), so the shift amounts and the "first quad of a group of eight" branch
+// are scalar: seven word stores per 32 plies, three 32-bit VALU operations per quad besides the store.  (A 64-bit
+// accumulator -- the obvious spelling -- made every field shift a v_lshlrev_b64: 106.6 instead of 95 us per 256 plies.)
+// One-lane form only.
 // PAIR: the two-lanes-per-env form for small batches (mnk_rollout_pair.hip): both lanes of a pair carry the env and
 // pick the move redundantly; lane `role` scans two of the four directions (one DPP swap ORs the verdicts), writes
 // half `role` of every record row and stores plane `role` of the final state.
@@ -50,8 +57,11 @@ struct RolloutLane {
   const char* rbase[OFF32 ? NW : 1] = {};  // SADDR / PAIR: rec_planes[.][w][0] / rec_meta as wave-uniform bases ...
   const char* mbase = nullptr;
   uint32_t roff = 0, moff = 0;  // ... and this lane's byte offsets of rec_planes[t][0][i] / rec_meta[t][i]
-  uint8_t* ra = nullptr;   // act_log[t / 4][i]
+  uint8_t* ra = nullptr;   // act_log[t / 4][i]  (ACT 3: the next word of the 7-bit stream, [w][i])
   uint64_t quad = 0;       // the actions of the current group of four plies
+  uint32_t q32 = 0;        // ACT 3: the same, 4 x 7 bits
+  uint32_t lo = 0;         // ACT 3: the stream's accumulator: the bits of the word being filled ...
+  uint32_t fill = 0;       // ... and how many of them are valid (wave-uniform: 0, 28, 24, ..., 4 between quads)
   // per-lane statistics, one add each per ply (T <= 65535 per launch): draws = done - wins, black wins =
   // wins - white wins; the summed length of the finished games needs no counter at all -- every ply adds one
   // to `moves` and a finished game takes its length out, so it is moves(start) + T - moves(end)
@@ -74,7 +84,8 @@ struct RolloutLane {
         moff = (uint32_t)i * 4u;
       }
     }
-    if (ACT) ra = (uint8_t*)act_log + i * 4 * ACT;
+    static_assert(ACT != 3 || (!PAIR && WS == 1), "the 7-bit action stream is built into the one-lane form only");
+    if (ACT) ra = (uint8_t*)act_log + i * 4 * (ACT == 3 ? 1 : ACT);
   }
 
   __device__ __forceinline__ void load(const uint64_t* planes, const uint32_t* meta, int64_t i) {
@@ -154,12 +165,33 @@ struct RolloutLane {
   }
 
   __device__ __forceinline__ void log_flush() {
+    if constexpr (ACT == 3) {  // 28 bits into the stream: the first quad of eight starts a word, every other completes one
+      if (fill == 0u) {
+        lo = q32;
+        fill = 28u;
+      } else {
+        *(uint32_t*)ra = lo | (q32 << fill);
+        ra += N * 4;
+        lo = q32 >> (32u - fill);
+        fill -= 4u;
+      }
+      q32 = 0;
+      return;
+    }
     if (WS == 1 || wrole == 0) {
       if (ACT == 1) *(uint32_t*)ra = (uint32_t)quad;
       if (ACT == 2) *(uint64_t*)ra = quad;
     }
     ra += N * 4 * ACT;
     quad = 0;
+  }
+
+  // end of the launch: a partly filled group of four (T not a multiple of 4), then what is left in the stream
+  __device__ __forceinline__ void log_finish(int T) {
+    if (ACT && (T & 3)) log_flush();
+    if constexpr (ACT == 3) {
+      if (fill) *(uint32_t*)ra = lo;
+    }
   }
 
   // uniform legal cell from one u32 (oracle/philox.py pick_legal; selfplay/policy.py:18-29): the action, and
@@ -187,7 +219,10 @@ struct RolloutLane {
   __device__ __forceinline__ void ply(uint32_t x, int field) {
     uint32_t hot[NW];
     const int a = pick(x, hot);
-    if (ACT) {
+    if constexpr (ACT == 3) {
+      q32 |= (uint32_t)a << (7 * field);
+      if (field == 3) log_flush();
+    } else if (ACT) {
       quad |= (uint64_t)(uint32_t)a << (8 * ACT * field);
       if (field == 3) log_flush();
     }
@@ -305,7 +340,7 @@ __device__ __forceinline__ void rollout_random_body(const MnkGeom& g, uint64_t* 
       const Philox4 blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
       for (uint32_t j = 0; t < T; ++t, ++j) L.ply(philox_word(blk, j), (int)j);
     }
-    if (ACT && (T & 3)) L.log_flush();  // T not a multiple of 4: the last word is partly filled
+    L.log_finish(T);  // T not a multiple of 4: the last word is partly filled
     L.store(planes, meta, i);
     if (stats) {
       const uint32_t len_sum = L.moves_in + (uint32_t)T - L.moves;

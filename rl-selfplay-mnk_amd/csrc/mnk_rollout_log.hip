@@ -19,7 +19,10 @@ void mnk_launch_rollout_log(const MnkGeom& g, uint64_t* planes, uint32_t* meta, 
                      (hipStream_t)stream, g, planes, meta, N, T, seed, step0, env_id0, rec_planes, rec_meta,          \
                      (unsigned long long*)stats, act_log)
     if (g.n == 19) MNK_SADDR(12, 19, 5, 2);                      // 361 cells: two bytes per action
-    else if (act_bytes == 1) {
+    else if (act_bytes == MNK_ACT_BITS7) {                        // 7-bit stream: boards of at most 128 cells
+      if (g.n == 9) MNK_SADDR(3, 9, 5, 3);
+      else MNK_SADDR(1, 3, 3, 3);
+    } else if (act_bytes == 1) {
       if (g.n == 9) MNK_SADDR(3, 9, 5, 1);
       else if (g.n == 3) MNK_SADDR(1, 3, 3, 1);
       else if (g.n == 13) MNK_SADDR(6, 13, 5, 1);
@@ -37,7 +40,16 @@ void mnk_launch_rollout_log(const MnkGeom& g, uint64_t* planes, uint32_t* meta, 
   MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NW, CN, CK, REC, ACTB>), grid, dim3(B), 0, \
                                      (hipStream_t)stream, g, planes, meta, N, T, seed, step0, env_id0,           \
                                      rec_planes, rec_meta, (unsigned long long*)stats, act_log))
-  if (rec && act_bytes == 1) MNK_ROLLOUT(true, 1);
+  if (act_bytes == MNK_ACT_BITS7) {
+    // boards of at most 128 cells: 9x9, 3x3 and generic boards of up to 8 register words (e.g. 11x11 = 121 cells, NW 5)
+#define MNK_ROLLOUT7(REC)                                                                                          \
+  MNK_DISPATCH_SMALL(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NW, CN, CK, REC, 3>), grid, dim3(B), 0, \
+                                           (hipStream_t)stream, g, planes, meta, N, T, seed, step0, env_id0,       \
+                                           rec_planes, rec_meta, (unsigned long long*)stats, act_log))
+    if (rec) MNK_ROLLOUT7(true);
+    else MNK_ROLLOUT7(false);
+#undef MNK_ROLLOUT7
+  } else if (rec && act_bytes == 1) MNK_ROLLOUT(true, 1);
   else if (rec) MNK_ROLLOUT(true, 2);
   else if (act_bytes == 1) MNK_ROLLOUT(false, 1);
   else MNK_ROLLOUT(false, 2);

@@ -19,6 +19,7 @@ ERR_NONE, ERR_ACTION_RANGE, ERR_ILLEGAL_MOVE = 0, 1, 2
 STEP_STRICT, STEP_AUTORESET = 1, 2
 LOGITS_F32, LOGITS_BF16 = 0, 1
 OBS_F32, OBS_BF16, OBS_U8 = 0, 1, 2
+ACT_U8, ACT_U16, ACT_BITS7 = 1, 2, 3
 COMM_ID_BYTES = 128
 SP_NEED_OPP, SP_WAS_RESET = 1, 2
 STREAM_MOVE, STREAM_OPP, STREAM_SIDE, STREAM_SAMPLE = 0, 1, 2, 3
@@ -53,6 +54,7 @@ SIGNATURES = {
     "mnk_selfplay_step_random": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _vp,
                                  _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     "mnk_rollout_random": [_vp, _vp, _i64, _i, _i, _i, _i, _u64, _u64, _i64, _vp, _vp, _vp, _vp, _i, _vp],
+    "mnk_action_log_words": [_i, _i],
     "mnk_replay_actions": [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "mnk_unpack_records": [_vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "mnk_gather_obs": [_vp, _i64, _i64, _i, _i, _vp, _i64, _vp, _i, _vp, _i, _vp, _vp],
@@ -65,6 +67,7 @@ SIGNATURES = {
     "mnk_allgather_records": [_vp, _vp, _vp, _i64, _vp],
     "mnk_comm_last_error": [],
     "mnk_comm_version": [],
+    "mnk_probe_record_writes": [_vp, _i64, _i, _i, _vp],
 }
 
 _STATUS = {-1: "invalid argument (null pointer / negative size)", -2: "unsupported board geometry",

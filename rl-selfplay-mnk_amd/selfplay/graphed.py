@@ -104,3 +104,121 @@ class GraphedAgentStep:
     def current_obs(self):
         """The observation the next step() will act on (static buffers)."""
         return {"observation": self.obs[self.cur], "action_mask": self.mask[self.cur]}
+
+
+class GraphedRollout:
+    """A whole rollout of ``buffer.n_steps`` agent-steps captured as ONE hipGraph whose nodes write straight into the
+    rows of the rollout buffer -- the loop of ``PPOAgent.learn`` (alg/ppo.py:93-122) with nothing left on the host.
+
+    A captured kernel's pointers are frozen, but a rollout fills the same buffer rows every time, so each step's node
+    can carry its own row pointers: step t reads observation / mask from row t, ``mnk_sample_logits`` writes actions and
+    log-probabilities into row t, the step kernels write rewards / terminated into row t and the next observation / mask
+    into row t+1 (the spill row after the last step).  The first node copies the spill row -- the observation carried
+    over from the previous rollout -- into row 0: the only copy of an observation in the whole rollout.
+
+        roll = GraphedRollout(wrapper, buffer, net)       # wrapper.reset() is done inside
+        for _ in range(iterations):
+            roll.run()                                    # buffer.ptr == n_steps afterwards
+            buffer.compute_advantages_and_returns(roll.last_values(), gamma, lam); ...update...; buffer.reset()
+
+    ``net(obs, None) -> (dist, values)`` as every reference architecture; ``net=None`` is the uniformly random agent
+    (``RandomPolicy``: the draw reads only the mask, values / log-probabilities of the uniform policy are written).
+    ``buffer``: ``alg.rollout_buffer.RolloutBuffer`` (dense rows) -- a ``PackedRolloutBuffer`` works with ``net=None``
+    or a net that is fed from ``obs_scratch`` (the dense observation then ping-pongs between two scratch slots).
+    Same kernels and random streams as the eager loop with ``FusedNNPolicy`` / ``RandomPolicy`` (seeded alike).
+    """
+
+    def __init__(self, wrapper, buffer, net=None, seed=None):
+        from selfplay.policy import default_key
+
+        self.wrapper, self.buffer, self.net = wrapper, buffer, net
+        self.dev = wrapper._dev
+        self.seed = default_key(seed)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.dense = hasattr(buffer, "observations")
+        env, n = wrapper.env, wrapper.num_envs
+        if not self.dense:  # packed buffer: the dense observation lives in two scratch slots
+            self.obs_scratch = [torch.empty((n, 2, env.m, env.n), dtype=env.obs_dtype, device=self.dev) for _ in range(2)]
+            self.mask_scratch = [torch.empty((n, env.max_moves), dtype=torch.bool, device=self.dev) for _ in range(2)]
+        buffer.reset()
+        steps = buffer.n_steps
+        spill = dict(buffer.row(steps))
+        if not self.dense:
+            spill.update(observation=self.obs_scratch[steps & 1], action_mask=self.mask_scratch[steps & 1])
+        wrapper.reset(out=spill)  # the first observation arrives where every later rollout finds its carried-over one
+        self.graph = None
+        self.recapture()
+
+    def _obs_of(self, t):
+        if self.dense:
+            r = self.buffer.row(t)
+            return r["observation"], r["action_mask"]
+        return self.obs_scratch[t & 1], self.mask_scratch[t & 1]
+
+    def _body(self):
+        w, buf = self.wrapper, self.buffer
+        n, steps = w.num_envs, buf.n_steps
+        src = buf.row(steps)
+        dst = buf.row(0)
+        for key in (("observation", "action_mask") if self.dense else ("packed",)):
+            dst[key].copy_(src[key])
+        if not self.dense and (steps & 1):  # the carried-over dense observation sits in slot steps & 1; step 0 reads slot 0
+            self.obs_scratch[0].copy_(self.obs_scratch[1])
+            self.mask_scratch[0].copy_(self.mask_scratch[1])
+        for t in range(steps):
+            obs, mask = self._obs_of(t)
+            row = buf.row(t)
+            logits = None
+            if self.net is not None:
+                with torch.no_grad():
+                    dist, values = self.net(obs, None)
+                    logits = dist.logits.contiguous()
+                    if logits.dtype not in (torch.float32, torch.bfloat16):
+                        logits = logits.to(torch.float32)
+                row["values"].copy_(values.reshape(-1))
+            mnk_hip.call("mnk_sample_logits", mnk_hip.ptr(logits),
+                         mnk_hip.LOGITS_BF16 if logits is not None and logits.dtype == torch.bfloat16 else mnk_hip.LOGITS_F32,
+                         mnk_hip.ptr(mask), n, mask.shape[1], self.seed, t, mnk_hip.ptr(self.step_dev), w.env_id0, 0,
+                         mnk_hip.ptr(row["actions"]), mnk_hip.ptr(row["log_probs"]), mnk_hip.stream_ptr(self.dev))
+            out = {"rewards": row["rewards"], "terminated": row["dones"]}
+            nobs, nmask = self._obs_of(t + 1)
+            out.update(observation=nobs, action_mask=nmask)
+            if not self.dense:
+                out["packed"] = buf.row(t + 1)["packed"]
+            # the Philox step of this node: the part that differs between the nodes of one rollout is baked in, the part
+            # that advances from rollout to rollout is read from step_dev
+            w.step_count = self._step0 + t
+            if self._opp_sampler is not None:
+                self._opp_sampler.calls = self._opp_calls0 + t
+            w._advance(row["actions"], w._forced_sides, out)
+        self.step_dev.add_(steps)
+
+    def recapture(self):
+        w = self.wrapper
+        w.step_dev = self.step_dev
+        self._step0 = w.step_count
+        self._opp_sampler = getattr(w.opponent_policy, "_sampler", None)
+        if self._opp_sampler is not None:
+            self._opp_sampler.step_dev = self.step_dev
+            self._opp_calls0 = self._opp_sampler.calls
+        side = torch.cuda.Stream(self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):  # one real rollout as the warm-up torch.cuda.graph asks for
+            self._body()
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body()
+        w.step_count = self._step0
+        if self._opp_sampler is not None:
+            self._opp_sampler.calls = self._opp_calls0
+        self.buffer.ptr = self.buffer.n_steps  # the warm-up rollout filled the buffer
+
+    def run(self):
+        self.graph.replay()
+        self.buffer.ptr = self.buffer.n_steps
+
+    def next_obs(self):
+        """observation / mask that follow the last step (``PPOAgent._last_obs``): feed the net for ``last_values``"""
+        obs, mask = self._obs_of(self.buffer.n_steps)
+        return {"observation": obs, "action_mask": mask}

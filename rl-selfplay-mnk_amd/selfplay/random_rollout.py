@@ -18,9 +18,14 @@ independent of the number of GPUs.  There is one exchange step, an all-gather ov
 process group (RCCL over xGMI when the backend is ``nccl``), in one of two formats:
 
   * ``gather_records``      the packed records themselves (28 B per env-step at 9x9);
-  * ``gather_action_logs``  the chunk-start state plus the action log (1-2 B per env-step):
-                            a rollout is a pure function of those, and ``replay_shard`` rebuilds
-                            any shard's full records bit-identically on the receiving GPU.
+  * ``gather_action_logs``  the action log (0.875 B per env-step on boards of up to 128 cells -- 7 bits per
+                            action --, 1 B up to 256 cells, 2 B beyond), with or without the chunk-start state:
+                            a rollout is a pure function of state + log, and ``replay_shard`` rebuilds any
+                            shard's full records bit-identically on the receiving GPU.  With the state in the
+                            message (``with_state=True``, +36 B per env and chunk at 9x9) any chunk can be replayed
+                            on its own; without it the receiver keeps every shard's replay state itself
+                            (``gather_start_state`` once, then every chunk replayed in order) and the log alone
+                            crosses the links.
 """
 from dataclasses import dataclass
 from typing import Optional
@@ -35,10 +40,12 @@ class RolloutRecords:
     planes: torch.Tensor  # int64 (u64 bits) [T, R, N], R = mnk_hip.record_words(m, n)
     meta: torch.Tensor    # int32 (u32 bits) [T, N]
     # only when the action log is on (alloc(..., log_actions=True)); all three are views into `msg`
-    act: Optional[torch.Tensor] = None      # action log, 4 plies per word: int32 / int64 [ceil(T/4), N]
-    meta0: Optional[torch.Tensor] = None    # env meta words at the start of the chunk, int32 [N]
-    planes0: Optional[torch.Tensor] = None  # env planes at the start of the chunk, int64 [2, W, N]
+    act: Optional[torch.Tensor] = None      # action log: int32 [words, N] (ACT_U8: 4 plies per word; ACT_BITS7: a 7-bit
+                                            # stream) or int64 [ceil(T/4), N] (ACT_U16)
+    meta0: Optional[torch.Tensor] = None    # env meta words at the start of the chunk, int32 [N]    (with_state only)
+    planes0: Optional[torch.Tensor] = None  # env planes at the start of the chunk, int64 [2, W, N]  (with_state only)
     msg: Optional[torch.Tensor] = None      # the one flat int64 buffer that is all-gathered
+    fmt: int = 0                            # ACT_U8 / ACT_U16 / ACT_BITS7 (mnk_hip.h MNK_ACT_*); 0 = no log
 
     @property
     def steps(self) -> int:
@@ -87,7 +94,10 @@ class RandomRollout:
         self.seed, self.env_id0, self.step = int(state["seed"]), int(state["env_id0"]), int(state["step"])
         self._stats.copy_(state["stats"])
 
-    def alloc(self, steps: int, log_actions: bool = False) -> RolloutRecords:
+    def alloc(self, steps: int, log_actions=False, with_state: bool = True) -> RolloutRecords:
+        """Record buffers for ``steps`` plies.  ``log_actions``: False, True (the most compact format the board allows:
+        7 bits per action up to 128 cells) or one of ACT_U8 / ACT_U16 / ACT_BITS7; ``with_state``: the chunk-start
+        planes / meta travel in the message too (a self-contained message), else the log alone."""
         env = self.env
         rec = RolloutRecords(
             planes=torch.empty((steps, mnk_hip.record_words(env.m, env.n), env.num_envs), dtype=torch.int64,
@@ -95,9 +105,14 @@ class RandomRollout:
             meta=torch.empty((steps, env.num_envs), dtype=torch.int32, device=env._dev),
         )
         if log_actions:
-            rec.msg = torch.zeros(_msg_words(env.words, env.num_envs, steps, env.max_moves), dtype=torch.int64,
+            fmt = action_log_format(env.max_moves) if log_actions is True else int(log_actions)
+            if fmt not in (ACT_U8, ACT_U16, ACT_BITS7) or (fmt == ACT_U8 and env.max_moves > 256) or \
+                    (fmt == ACT_BITS7 and env.max_moves > 128):
+                raise ValueError(f"action-log format {fmt} does not fit a board of {env.max_moves} cells")
+            rec.fmt = fmt
+            rec.msg = torch.zeros(_msg_words(env.words, env.num_envs, steps, fmt, with_state), dtype=torch.int64,
                                   device=env._dev)
-            rec.planes0, rec.act, rec.meta0 = _msg_views(rec.msg, env.words, env.num_envs, steps, env.max_moves)
+            rec.planes0, rec.act, rec.meta0 = _msg_views(rec.msg, env.words, env.num_envs, steps, fmt, with_state)
         return rec
 
     def run(self, steps: int, out: Optional[RolloutRecords] = None, record: bool = True) -> Optional[RolloutRecords]:
@@ -117,69 +132,132 @@ class RandomRollout:
             mnk_hip.call("mnk_rollout_random", mnk_hip.ptr(env._planes), mnk_hip.ptr(env._meta), env.num_envs,
                          env.m, env.n, env.k, steps, self.seed, self.step, self.env_id0,
                          mnk_hip.ptr(out.planes) if record else None, mnk_hip.ptr(out.meta) if record else None,
-                         mnk_hip.ptr(self._stats), mnk_hip.ptr(act), act.element_size() // 4 if act is not None else 0,
-                         env._stream())
+                         mnk_hip.ptr(self._stats), mnk_hip.ptr(act), out.fmt if act is not None else 0, env._stream())
         self.step += steps
         return out if record else None
 
 
-def action_log_dtype(num_actions: int):
-    """The log packs four plies per word: int32 words (one byte per action) while the board has at most
-    256 cells, int64 words (16 bits per action) beyond."""
-    return torch.int32 if num_actions <= 256 else torch.int64
+ACT_U8, ACT_U16, ACT_BITS7 = 1, 2, 3  # include/mnk_hip.h MNK_ACT_*
 
 
-def unpack_action_log(act: torch.Tensor, steps: int) -> torch.Tensor:
-    """[ceil(T/4), N] packed log -> int64 actions [T, N]"""
-    bits = 8 if act.dtype == torch.int32 else 16
+def action_log_format(num_actions: int, compact: bool = True) -> int:
+    """The most compact log format a board of ``num_actions`` cells allows: 7 bits per action up to 128 cells (only with
+    ``compact``), one byte up to 256, two bytes beyond."""
+    if compact and num_actions <= 128:
+        return ACT_BITS7
+    return ACT_U8 if num_actions <= 256 else ACT_U16
+
+
+def action_log_words(fmt: int, steps: int) -> int:
+    """32-bit words per env of a ``steps``-ply log (= mnk_action_log_words)"""
+    q = (steps + 3) // 4
+    return {ACT_U8: q, ACT_U16: 2 * q, ACT_BITS7: (7 * q + 7) // 8}[fmt]
+
+
+def unpack_action_log(act: torch.Tensor, steps: int, fmt: Optional[int] = None) -> torch.Tensor:
+    """packed log -> int64 actions [T, N] (``fmt`` defaults to ACT_U8 for an int32 log, ACT_U16 for an int64 one)"""
+    if fmt is None:
+        fmt = ACT_U8 if act.dtype == torch.int32 else ACT_U16
+    if fmt == ACT_BITS7:
+        words = act.to(torch.int64) & 0xFFFFFFFF  # [W, N] u32 values
+        t = torch.arange(steps, device=act.device)
+        bit = 7 * t
+        w, sh = bit // 32, bit % 32
+        lo = words[w]
+        hi = words[torch.clamp(w + 1, max=words.shape[0] - 1)]
+        return (((lo | (hi << 32)) >> sh.unsqueeze(1)) & 0x7F).to(torch.int64)
+    bits = 8 if fmt == ACT_U8 else 16
     fields = [(act >> (bits * j)) & ((1 << bits) - 1) for j in range(4)]
     return torch.stack(fields, dim=1).reshape(-1, act.shape[1])[:steps].to(torch.int64)
 
 
-def _msg_layout(words: int, nenv: int, steps: int, num_actions: int):
-    """Offsets (in int64 words) of the three parts of the exchange message: planes0 | act | meta0."""
-    act_bytes = ((steps + 3) // 4) * nenv * (4 if num_actions <= 256 else 8)
-    n_planes = 2 * words * nenv
+def _msg_layout(words: int, nenv: int, steps: int, fmt: int, with_state: bool):
+    """Sizes (in int64 words) of the three parts of the exchange message: planes0 | act | meta0 (the first and the
+    last only ``with_state``)."""
+    act_bytes = action_log_words(fmt, steps) * nenv * 4
+    n_planes = 2 * words * nenv if with_state else 0
     n_act = (act_bytes + 7) // 8
-    n_meta = (nenv * 4 + 7) // 8
+    n_meta = (nenv * 4 + 7) // 8 if with_state else 0
     return n_planes, n_act, n_meta
 
 
-def _msg_words(words, nenv, steps, num_actions) -> int:
-    return sum(_msg_layout(words, nenv, steps, num_actions))
+def _msg_words(words, nenv, steps, fmt, with_state=True) -> int:
+    return sum(_msg_layout(words, nenv, steps, fmt, with_state))
 
 
-def _msg_views(msg, words, nenv, steps, num_actions):
-    """(planes0 [.., 2, W, N] int64, act [.., ceil(T/4), N] int32/int64, meta0 [.., N] int32) views of a message
-    buffer whose last dimension is the flat message (leading dimensions, e.g. the rank axis, are kept)."""
-    n_planes, n_act, n_meta = _msg_layout(words, nenv, steps, num_actions)
+def _msg_views(msg, words, nenv, steps, fmt, with_state=True):
+    """(planes0 [.., 2, W, N] int64, act [.., words, N] int32 / [.., ceil(T/4), N] int64, meta0 [.., N] int32) views of
+    a message buffer whose last dimension is the flat message (leading dimensions, e.g. the rank axis, are kept);
+    planes0 / meta0 are None for a log-only message."""
+    n_planes, n_act, n_meta = _msg_layout(words, nenv, steps, fmt, with_state)
     lead = msg.shape[:-1]
     q = (steps + 3) // 4
-    planes0 = msg[..., :n_planes].reshape(lead + (2, words, nenv))
+    planes0 = msg[..., :n_planes].reshape(lead + (2, words, nenv)) if with_state else None
     act64 = msg[..., n_planes:n_planes + n_act]
-    if num_actions <= 256:
-        act = act64.view(torch.int32)[..., :q * nenv].reshape(lead + (q, nenv))
-    else:
+    if fmt == ACT_U16:
         act = act64[..., :q * nenv].reshape(lead + (q, nenv))
-    meta0 = msg[..., n_planes + n_act:].view(torch.int32)[..., :nenv]
+    else:
+        aw = action_log_words(fmt, steps)
+        act = act64.view(torch.int32)[..., :aw * nenv].reshape(lead + (aw, nenv))
+    meta0 = msg[..., n_planes + n_act:].view(torch.int32)[..., :nenv] if with_state else None
     return planes0, act, meta0
 
 
 @dataclass
 class GatheredLogs:
-    """What ``gather_action_logs`` leaves on every rank: per shard r the chunk-start state and the log,
-    as views of the gathered message buffer ``msg`` [world, L]."""
-    planes0: torch.Tensor  # int64 [world, 2, W, N]
-    meta0: torch.Tensor    # int32 [world, N]
-    act: torch.Tensor      # int32 / int64 [world, ceil(T/4), N]: four plies per word
-    steps: int = 0         # T
+    """What ``gather_action_logs`` leaves on every rank: per shard r the log (and, in a self-contained message, the
+    chunk-start state), as views of the gathered message buffer ``msg`` [world, L]."""
+    planes0: Optional[torch.Tensor]  # int64 [world, 2, W, N]; None for log-only messages
+    meta0: Optional[torch.Tensor]    # int32 [world, N]; None for log-only messages
+    act: torch.Tensor                # int32 [world, words, N] / int64 [world, ceil(T/4), N]
+    steps: int = 0                   # T
     msg: Optional[torch.Tensor] = None
+    fmt: int = ACT_U8
 
     @staticmethod
-    def empty(world: int, words: int, nenv: int, steps: int, num_actions: int, device) -> "GatheredLogs":
-        msg = torch.empty((world, _msg_words(words, nenv, steps, num_actions)), dtype=torch.int64, device=device)
-        planes0, act, meta0 = _msg_views(msg, words, nenv, steps, num_actions)
-        return GatheredLogs(planes0=planes0, meta0=meta0, act=act, steps=steps, msg=msg)
+    def empty(world: int, words: int, nenv: int, steps: int, num_actions: int, device, fmt: Optional[int] = None,
+              with_state: bool = True) -> "GatheredLogs":
+        """``fmt`` defaults to the byte / two-byte format of ``num_actions`` (the round-2 message)"""
+        if fmt is None:
+            fmt = action_log_format(num_actions, compact=False)
+        msg = torch.empty((world, _msg_words(words, nenv, steps, fmt, with_state)), dtype=torch.int64, device=device)
+        planes0, act, meta0 = _msg_views(msg, words, nenv, steps, fmt, with_state)
+        return GatheredLogs(planes0=planes0, meta0=meta0, act=act, steps=steps, msg=msg, fmt=fmt)
+
+
+@dataclass
+class ReplayState:
+    """Every shard's env state on this rank, advanced by ``replay_shard`` chunk after chunk: what lets the ranks
+    exchange the action log alone.  ``gather_start_state`` fills it once, before the first chunk."""
+    planes: torch.Tensor  # int64 [world, 2, W, N]
+    meta: torch.Tensor    # int32 [world, N]
+    msg: torch.Tensor     # the gathered buffer the two are views of
+
+
+def gather_start_state(env, group=None, exchange=None, stream=None) -> ReplayState:
+    """All-gather of every shard's current env state (planes | meta: 36 B per env at 9x9), once: afterwards a rank
+    that replays every chunk of a shard in order (``replay_shard(..., state=...)``) always holds that shard's
+    chunk-start state, and the per-chunk message is the log alone."""
+    n, w = env.num_envs, env.words
+    n_planes, n_meta = 2 * w * n, (n * 4 + 7) // 8
+    send = torch.zeros(n_planes + n_meta, dtype=torch.int64, device=env._dev)
+    send[:n_planes].copy_(env._planes.reshape(-1))
+    send[n_planes:].view(torch.int32)[:n].copy_(env._meta)
+    if exchange is not None:
+        world = exchange.world
+    else:
+        import torch.distributed as dist
+
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    recv = torch.empty((world, send.numel()), dtype=torch.int64, device=env._dev)
+    if exchange is not None:
+        exchange.all_gather(send, recv.view(-1), stream)
+    elif world > 1:
+        dist.all_gather_into_tensor(recv.view(-1), send, group=group)
+    else:
+        recv[0].copy_(send)
+    return ReplayState(planes=recv[:, :n_planes].reshape(world, 2, w, n),
+                       meta=recv[:, n_planes:].view(torch.int32)[:, :n], msg=recv)
 
 
 def gather_action_logs(rec: RolloutRecords, group=None, out: Optional[GatheredLogs] = None, exchange=None,
@@ -198,11 +276,11 @@ def gather_action_logs(rec: RolloutRecords, group=None, out: Optional[GatheredLo
 
         world = dist.get_world_size(group)
     t, n = rec.meta.shape
-    w = rec.planes0.shape[1]  # the chunk-start state travels in the state layout [2, W, N]
-    num_actions = 256 if rec.act.dtype == torch.int32 else 65536
+    with_state = rec.planes0 is not None
+    w = rec.planes0.shape[1] if with_state else 0  # the chunk-start state travels in the state layout [2, W, N]
     if out is None:
-        out = GatheredLogs.empty(world, w, n, t, num_actions, rec.msg.device)
-    assert out.msg.shape == (world, rec.msg.numel()) and out.steps == t
+        out = GatheredLogs.empty(world, w, n, t, 0, rec.msg.device, fmt=rec.fmt, with_state=with_state)
+    assert out.msg.shape == (world, rec.msg.numel()) and out.steps == t and out.fmt == rec.fmt
     if exchange is not None:
         exchange.all_gather(rec.msg, out.msg.view(-1), stream)
     else:
@@ -211,31 +289,41 @@ def gather_action_logs(rec: RolloutRecords, group=None, out: Optional[GatheredLo
 
 
 def replay_shard(logs: GatheredLogs, shard: int, m: int, n: int, k: int, err: Optional[torch.Tensor] = None,
-                 out: Optional[RolloutRecords] = None, scratch=None) -> RolloutRecords:
-    """Rebuilds shard ``shard``'s full packed records from its gathered state + action log
+                 out: Optional[RolloutRecords] = None, scratch=None, state: Optional[ReplayState] = None,
+                 record: bool = True) -> Optional[RolloutRecords]:
+    """Rebuilds shard ``shard``'s full packed records from its chunk-start state + action log
     (``mnk_replay_actions``, one launch); bit-identical to what the owning rank recorded.
-    ``scratch``: optional ``(planes int64 [2, W, N], meta int32 [N])`` buffers for the state the replay advances
-    (reused across calls instead of two fresh copies)."""
+    The state comes from the message itself (self-contained messages: a copy is advanced, ``scratch`` = optional
+    ``(planes int64 [2, W, N], meta int32 [N])`` buffers for it) or from ``state`` (log-only messages: the shard's
+    entry of the ``ReplayState`` is advanced IN PLACE, so every chunk must be replayed, in order, exactly once;
+    ``record=False`` only advances the state)."""
     act = logs.act[shard]
     t, nenv = logs.steps, act.shape[1]
-    assert act.shape[0] == (t + 3) // 4, "GatheredLogs.steps does not match the packed log"
+    assert act.shape[0] == (action_log_words(logs.fmt, t) if logs.fmt != ACT_U16 else (t + 3) // 4), \
+        "GatheredLogs.steps does not match the packed log"
     dev = act.device
-    if scratch is not None:
+    if state is not None:
+        planes, meta = state.planes[shard], state.meta[shard]
+    elif logs.planes0 is None:
+        raise ValueError("log-only messages need the receiver's ReplayState (gather_start_state)")
+    elif scratch is not None:
         planes, meta = scratch
         planes.copy_(logs.planes0[shard])
         meta.copy_(logs.meta0[shard])
     else:
         planes = logs.planes0[shard].clone()
         meta = logs.meta0[shard].clone()
-    if out is None:
+    if not record:
+        out = None
+    elif out is None:
         out = RolloutRecords(planes=torch.empty((t, mnk_hip.record_words(m, n), nenv), dtype=torch.int64, device=dev),
                              meta=torch.empty((t, nenv), dtype=torch.int32, device=dev))
     if err is None:
         err = torch.zeros(2, dtype=torch.int32, device=dev)
     if t and nenv:
         mnk_hip.call("mnk_replay_actions", mnk_hip.ptr(planes), mnk_hip.ptr(meta), nenv, m, n, k, t,
-                     mnk_hip.ptr(act), act.element_size() // 4, mnk_hip.ptr(out.planes), mnk_hip.ptr(out.meta),
-                     mnk_hip.ptr(err), mnk_hip.stream_ptr(dev))
+                     mnk_hip.ptr(act), logs.fmt, mnk_hip.ptr(out.planes if out is not None else None),
+                     mnk_hip.ptr(out.meta if out is not None else None), mnk_hip.ptr(err), mnk_hip.stream_ptr(dev))
     return out
 
 

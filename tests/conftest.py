@@ -27,3 +27,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def random_play_stats(board: str) -> dict:
+    """Known-answer statistics of uniform random play on ``board`` ("9x9x5"), recorded from the imported reference by
+    tests/golden/make_golden_stats.py (first games only, >= 3e5 of them): games, mean_plies, sd_plies, se_mean_plies,
+    draws, draw_rate, se_draw_rate, black_wins, white_wins."""
+    import numpy as np
+
+    data = np.load(os.path.join(GOLDEN, "random_play_stats.npz"))
+    return dict(zip((str(f) for f in data["fields"]), (float(v) for v in data[board])))

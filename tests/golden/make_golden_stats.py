@@ -29,7 +29,7 @@ from env.torch_vector_mnk_env import TorchVectorMnkEnv  # noqa: E402
 from selfplay.policy import RandomPolicy  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
-BOARDS = [(3, 3, 3), (9, 9, 5), (19, 19, 5)]
+BOARDS = [(3, 3, 3), (9, 9, 5), (12, 12, 5), (19, 19, 5)]
 SEED = 20260104
 BATCH = 16384
 
@@ -69,9 +69,9 @@ def main():
     games = int(sys.argv[1]) if len(sys.argv) > 1 else 327680
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     out = {"seed": np.int64(SEED), "boards": np.array(BOARDS, dtype=np.int32)}
-    for j, (m, n, k) in enumerate(BOARDS):
+    for (m, n, k) in BOARDS:
         t0 = time.time()
-        length, outcome = first_games(m, n, k, games, SEED + j)
+        length, outcome = first_games(m, n, k, games, SEED + m * 10000 + n * 100 + k)  # a seed per board, not per position in the list
         g = length.size
         mean, sd = float(length.mean()), float(length.std(ddof=1))
         draws, black, white = (int((outcome == v).sum()) for v in (0, 1, 2))

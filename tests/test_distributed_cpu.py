@@ -39,27 +39,46 @@ def _worker(rank, world, port, m, n, k, nenv, steps, seed, out_dir):
         full = gather_records(rec)
         assert full.planes.shape == (steps, planes.shape[1], world * nenv)
         assert full.meta.shape == (steps, world * nenv)
-        # the compact exchange format: chunk-start state + action log
-        from selfplay.random_rollout import gather_action_logs
-        from selfplay.random_rollout import unpack_action_log
-        acts = (meta & 0xFFFF).astype(np.int64)
-        pad = np.zeros(((-steps) % 4, nenv), dtype=np.int64)
-        quads = np.concatenate([acts, pad]).reshape(-1, 4, nenv)
-        from selfplay.random_rollout import _msg_views, _msg_words
+        # the compact exchange formats: the action log as bytes / a 7-bit stream, with the chunk-start state in the
+        # message or alone (then every rank holds every shard's replay state, gathered once before the first chunk)
         from oracle.packing import words_per_plane
+        from oracle.rollout import encode_action_log
+        from selfplay.random_rollout import (ACT_BITS7, ACT_U8, _msg_views, _msg_words, action_log_words,
+                                             gather_action_logs, unpack_action_log)
+        acts = (meta & 0xFFFF).astype(np.int64)
         words = words_per_plane(m, n)
-        rec.msg = torch.zeros(_msg_words(words, nenv, steps, m * n), dtype=torch.int64)
-        rec.planes0, rec.act, rec.meta0 = _msg_views(rec.msg, words, nenv, steps, m * n)
-        rec.act.copy_(torch.from_numpy((quads[:, 0] | quads[:, 1] << 8 | quads[:, 2] << 16 | quads[:, 3] << 24).astype(np.int32)))
-        rec.planes0.zero_()  # state layout [2, W, N]; every env starts from an empty board
-        assert not rec.planes[0].any()
-        rec.meta0.zero_()  # every env starts from reset
-        logs = gather_action_logs(rec)
-        assert logs.act.shape == (world, (steps + 3) // 4, nenv) and logs.planes0.shape[0] == world and logs.steps == steps
-        assert torch.equal(logs.act[rank], rec.act) and torch.equal(logs.planes0[rank], rec.planes0)
+        for fmt in ([ACT_U8, ACT_BITS7] if m * n <= 128 else [ACT_U8]):
+            for with_state in (True, False):
+                rec.fmt = fmt
+                rec.msg = torch.zeros(_msg_words(words, nenv, steps, fmt, with_state), dtype=torch.int64)
+                rec.planes0, rec.act, rec.meta0 = _msg_views(rec.msg, words, nenv, steps, fmt, with_state)
+                rec.act.copy_(torch.from_numpy(encode_action_log(acts, fmt).view(np.int32)))
+                if with_state:
+                    rec.planes0.zero_()  # state layout [2, W, N]; every env starts from an empty board
+                    assert not rec.planes[0].any()
+                    rec.meta0.zero_()  # every env starts from reset
+                else:
+                    assert rec.planes0 is None and rec.msg.numel() * 8 == (action_log_words(fmt, steps) * nenv * 4 + 7) // 8 * 8
+                logs = gather_action_logs(rec)
+                assert logs.act.shape == (world, action_log_words(fmt, steps), nenv) and logs.steps == steps and logs.fmt == fmt
+                assert (logs.planes0 is not None) == with_state and (not with_state or logs.planes0.shape[0] == world)
+                assert torch.equal(logs.act[rank], rec.act)
+                for r in range(world):
+                    assert torch.equal(unpack_action_log(logs.act[r], steps, fmt),
+                                       (full.meta[:, r * nenv:(r + 1) * nenv] & 0xFFFF).to(torch.int64))
+        # the replay state every rank keeps when the log travels alone: gathered once, before the first chunk
+        from types import SimpleNamespace
+
+        from selfplay.random_rollout import gather_start_state
+        fake_env = SimpleNamespace(num_envs=nenv, words=words, _dev=torch.device("cpu"),
+                                   _planes=torch.full((2, words, nenv), rank + 1, dtype=torch.int64),
+                                   _meta=torch.full((nenv,), rank + 5, dtype=torch.int32))
+        start = gather_start_state(fake_env)
+        assert start.planes.shape == (world, 2, words, nenv) and start.meta.shape == (world, nenv)
         for r in range(world):
-            assert torch.equal(unpack_action_log(logs.act[r], steps),
-                               (full.meta[:, r * nenv:(r + 1) * nenv] & 0xFFFF).to(torch.int64))
+            assert bool((start.planes[r] == r + 1).all()) and bool((start.meta[r] == r + 5).all())
+        if m * n <= 128:  # 0.875 B per env-step on the wire (+ nothing else once the receivers hold the state)
+            assert action_log_words(ACT_BITS7, 256) * 4 / 256 == 0.875
         totals = torch.from_numpy(stats)
         dist.all_reduce(totals)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), planes=full.planes.numpy(), meta=full.meta.numpy(),

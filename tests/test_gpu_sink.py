@@ -329,3 +329,80 @@ def test_step_random_is_sample_step_reset_observe_in_one_launch(hip, m, n, k, ne
     for t in range(c + 2):
         e.step_random_into(r1, d1, seed=seed, step=t, autoreset=False)
     assert int(e.move_counts.min()) == c + 2
+
+
+# ----------------------------------------------------------------------------- the whole rollout as one hipGraph
+@pytest.mark.parametrize("agent,opponent,packed", [("random", "random", False), ("net", "nn", False), ("random", "random", True),
+                                                   ("net", "random", True)])
+def test_graphed_rollout_fills_the_buffer_like_the_eager_loop(hip, agent, opponent, packed):
+    """selfplay/graphed.py GraphedRollout: n_steps agent-steps as one captured graph writing into the buffer's rows ==
+    the eager PPO loop (net -> fused draw -> wrapper.step -> buffer.add) with the same seeds, rollout after rollout
+    (the observation carried over between rollouts included)."""
+    import copy
+
+    import torch.nn as nn
+
+    from selfplay.graphed import GraphedRollout
+
+    m, n, k, nenv, c, steps, rollouts = 3, 3, 3, 200, 9, 7, 3  # an odd number of steps: the scratch slots swap roles
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.body = nn.Sequential(nn.Flatten(), nn.Linear(2 * c, 32), nn.Tanh())
+            self.pi, self.v = nn.Linear(32, c), nn.Linear(32, 1)
+
+        def forward(self, obs, action_mask=None):
+            h = self.body(obs)
+            return torch.distributions.Categorical(logits=self.pi(h), validate_args=False), torch.tanh(self.v(h))
+
+    torch.manual_seed(1)
+    net = Net().to(DEV).eval() if agent == "net" else None
+    opp_net = Net().to(DEV).eval()
+
+    def make():
+        w = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV), seed=5)
+        w.set_opponent(hip.policy.RandomPolicy(c, seed=3) if opponent == "random"
+                       else hip.policy.FusedNNPolicy(copy.deepcopy(opp_net), seed=3))
+        buf = hip.PackedBuffer(steps, nenv, m, n, device=DEV) if packed else hip.Buffer(steps, nenv, (2, m, n), c, device=DEV)
+        return w, buf
+
+    w, buf = make()
+    roll = GraphedRollout(w, buf, net, seed=11)   # plays one rollout while warming up
+    # the eager twin
+    w2, buf2 = make()
+    w2.attach_sink(buf2)
+    sampler = hip.policy._HipSampler(seed=11)
+    obs, _ = w2.reset()
+    dense_obs = []
+    for r in range(rollouts):
+        if r:
+            roll.run()
+            buf2.reset()
+        for t in range(steps):
+            if net is not None:
+                with torch.no_grad():
+                    dist, values = net(obs["observation"], None)
+                logits = dist.logits
+            else:
+                logits, values = None, torch.zeros(nenv, 1, device=DEV)
+            actions, logp = sampler.draw(logits, obs["action_mask"], False, want_logp=True)
+            # the packed planes of the observation acted on: where reset() / the previous step put them (the spill row
+            # after the last step of a rollout, copied into row 0 by add)
+            cur_packed = buf2.row(steps if (r and t == 0) else t).get("packed")
+            nxt, rew, term, trunc, _ = w2.step(actions)
+            if packed:
+                buf2.add(cur_packed, actions, rew, values, logp, term | trunc)
+            else:
+                buf2.add(obs["observation"], actions, rew, values, logp, term | trunc, obs["action_mask"])
+            obs = nxt
+        where = f"rollout {r}"
+        assert buf.ptr == steps
+        for name in ("actions", "rewards", "dones", "log_probs") + (("values",) if net is not None else ()):
+            assert torch.equal(getattr(buf, name), getattr(buf2, name)), (where, name)
+        if packed:
+            assert torch.equal(buf.planes, buf2.planes), where
+        else:
+            assert torch.equal(buf.observations, buf2.observations) and torch.equal(buf.action_masks, buf2.action_masks), where
+        nxt_graph = roll.next_obs()
+        assert torch.equal(nxt_graph["observation"], obs["observation"]) and torch.equal(nxt_graph["action_mask"], obs["action_mask"]), where
