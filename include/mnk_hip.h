@@ -116,6 +116,10 @@ extern "C" {
 #define MNK_STREAM_SAMPLE 3
 
 int mnk_abi_version(void);
+/* Developer knobs (MNK_ROLLOUT_PAIR, MNK_ROLLOUT_FORM, MNK_JIT, MNK_ROLLOUT_SADDR, MNK_EMIT_ENVS, MNK_EMIT_THREADS: A/B
+ * timing and parity tests of every kernel form) are read from the environment once, at the first call that needs them;
+ * this reads them again.  Not meant to race with launches from other threads. */
+int mnk_reload_config(void);
 /* W = ceil(m*(n+1)/64), or 0 when the geometry is unsupported */
 int mnk_state_words(int m, int n);
 /* R = ceil(m*(n+1)/32), rows of one rollout record; 0 when the geometry is unsupported */

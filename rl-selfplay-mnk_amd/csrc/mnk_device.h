@@ -178,11 +178,15 @@ __device__ __forceinline__ int bs_select_hot(const uint32_t (&x)[NW], int r_, ui
   }
   const uint32_t pos = (uint32_t)select_bit32(word, (int)(r - before));
   const uint32_t one = 1u << pos;
+  // past[] is monotone (past[w + 1] implies past[w]): with a[w] = past[w] ? one : 0 the chosen word is where a[] drops,
+  // hot[w] = a[w] ^ a[w + 1] -- one select and one xor per word boundary instead of two selects
+  uint32_t a[NW + 1];
+  a[0] = one;
+  a[NW] = 0u;
 #pragma unroll
-  for (int w = 0; w < NW; ++w) {
-    const uint32_t h = (w == 0 || past[w]) ? one : 0u;
-    hot[w] = (w + 1 < NW && past[w + 1]) ? 0u : h;
-  }
+  for (int w = 1; w < NW; ++w) a[w] = past[w] ? one : 0u;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) hot[w] = a[w] ^ a[w + 1];
   return (int)(base + pos);
 }
 

@@ -62,31 +62,57 @@ inline int mnk_launch_status(const char* what) {
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// Developer knobs from the environment (A/B timing, parity tests of every kernel form), read ONCE -- a launch used to
+// cost four or five getenv() calls, which is nothing beside a 90 us rollout launch but not beside a 5 us step.
+// mnk_reload_config() (C ABI; mnk_hip.reload_config() in Python) reads them again after the environment has changed.
+struct MnkConfig {
+  int pair_override = -1;  // MNK_ROLLOUT_PAIR=0/1: never / always two lanes per env (unset: by batch size)
+  int form = 0;            // MNK_ROLLOUT_FORM=lane|pair|pairw|ws2|ws4 -> 1..5 (unset / unknown: 0)
+  int jit = -1;            // MNK_JIT=0/1 (unset: run-time specialisation from 2^20 env-steps per launch)
+  bool saddr_off = false;  // MNK_ROLLOUT_SADDR=0: no 32-bit-offset record stores
+  int emit_envs = 0;       // MNK_EMIT_ENVS=16|32|64: envs per workgroup of the write-out kernels (0: by batch size)
+  int emit_threads = 256;  // MNK_EMIT_THREADS=64|128|256 (the kernels are __launch_bounds__(256))
+};
+enum { MNK_FORM_NONE = 0, MNK_FORM_LANE, MNK_FORM_PAIR, MNK_FORM_PAIRW, MNK_FORM_WS2, MNK_FORM_WS4 };
+
+inline const MnkConfig& mnk_config(bool reload = false) {
+  static MnkConfig cfg;
+  static bool loaded = false;
+  if (!loaded || reload) {
+    MnkConfig c;
+    if (const char* v = getenv("MNK_ROLLOUT_PAIR")) c.pair_override = atoi(v) != 0 ? 1 : 0;
+    if (const char* v = getenv("MNK_ROLLOUT_FORM")) {
+      static const char* names[] = {"", "lane", "pair", "pairw", "ws2", "ws4"};
+      for (int f = 1; f <= 5; ++f)
+        if (!strcmp(v, names[f])) c.form = f;
+    }
+    if (const char* v = getenv("MNK_JIT")) c.jit = atoi(v) != 0 ? 1 : 0;
+    if (const char* v = getenv("MNK_ROLLOUT_SADDR")) c.saddr_off = atoi(v) == 0;
+    if (const char* v = getenv("MNK_EMIT_ENVS")) {
+      const int t = atoi(v);
+      c.emit_envs = (t == 16 || t == 32 || t == 64) ? t : 0;
+    }
+    if (const char* v = getenv("MNK_EMIT_THREADS")) {
+      const int t = atoi(v);
+      c.emit_threads = (t == 64 || t == 128 || t == 256) ? t : 256;  // anything else would break the launch bounds
+    }
+    cfg = c;
+    loaded = true;
+  }
+  return cfg;
+}
+
 // envs per workgroup of the kernels with a write-out stage; `items` = envs (x plies for mnk_unpack_records) of the launch.
 // 64 by default; 32 while that still leaves fewer than 1 024 workgroups (19x19x5 x 32 768 envs: 25.5 vs 26.9 us for
 // the fused self-play step, tools/exp_kernels.py).  MNK_EMIT_ENVS=16|32|64 forces one (read once per process).
 inline int mnk_block_envs(int64_t items) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* v = getenv("MNK_EMIT_ENVS");
-    const int t = v ? atoi(v) : 0;
-    forced = (t == 16 || t == 32 || t == 64) ? t : 0;
-  }
-  if (forced) return forced;
+  if (const int forced = mnk_config().emit_envs) return forced;
   return items <= 32768 ? 32 : 64;
 }
 
 // threads per workgroup of those kernels: the first 64 lanes play their envs, then all waves of
 // the workgroup sweep its output slab (more waves per SIMD to hide the LDS / store latency)
-inline int mnk_block_threads() {
-  static int cached = 0;
-  if (!cached) {
-    const char* v = getenv("MNK_EMIT_THREADS");
-    int t = v ? atoi(v) : 256;
-    cached = (t == 64 || t == 128 || t == 256) ? t : 256;  // kernels are __launch_bounds__(256)
-  }
-  return cached;
-}
+inline int mnk_block_threads() { return mnk_config().emit_threads; }
 
 // Kernel variants: NW = u32 register words per plane; CN / CK = compile-time board width and
 // run length (0 = run time).  The boards people actually train on get fully specialised code
@@ -123,8 +149,7 @@ inline int mnk_block_threads() {
 // may the one-lane rollout address its record stores with 32-bit lane offsets (SADDR form)?  Only while a wave is
 // alone on its SIMD (where it measured faster) and a launch's record rows stay below 4 GiB
 inline bool mnk_rollout_saddr_ok(const MnkGeom& g, int64_t N, int T) {
-  const char* v = getenv("MNK_ROLLOUT_SADDR");  // "0" switches the form off (A/B timing; read per call)
-  if (v && atoi(v) == 0) return false;
+  if (mnk_config().saddr_off) return false;  // MNK_ROLLOUT_SADDR=0 switches the form off (A/B timing)
   return N <= 65536 && ((int64_t)T * g.NW + 1) * N * 8 < (1ll << 32);
 }
 

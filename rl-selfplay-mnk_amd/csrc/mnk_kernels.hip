@@ -557,6 +557,11 @@ int mnk_probe_record_writes(uint64_t* rec, int64_t N, int T, int rows, void* str
 
 int mnk_abi_version(void) { return MNK_ABI_VERSION; }
 
+int mnk_reload_config(void) {
+  mnk_config(true);
+  return MNK_OK;
+}
+
 int mnk_record_words(int m, int n) {
   MnkGeom g;
   if (mnk_check_geom(m, n, 1, &g) != MNK_OK) return 0;

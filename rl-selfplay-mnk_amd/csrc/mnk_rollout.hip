@@ -114,8 +114,8 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   // two lanes per env only while both lanes of every env still fit one wave per SIMD (2N <= 65 536 lanes:
   // 9x9x5 106 vs 135 us per 256 plies at 32 768 envs, 164 vs 135 at 36 864; tools/exp_pair_threshold.py)
   // (MNK_ROLLOUT_PAIR=0/1 overrides, for A/B timing)
-  const char* pair_env = getenv("MNK_ROLLOUT_PAIR");  // read per call, so one process can time / test both forms
-  const int pair_override = pair_env ? atoi(pair_env) : -1;
+  const MnkConfig& cfg = mnk_config();  // environment knobs, read once (mnk_reload_config() re-reads them)
+  const int pair_override = cfg.pair_override;
   const bool pair_geom = (g.n == 9 && g.k == 5 && g.NW == 3) || (g.n == 3 && g.k == 3 && g.NW == 1) ||
                          (g.n == 13 && g.k == 5 && g.NW == 6) || (g.n == 15 && g.k == 5 && g.NW == 8) ||
                          (g.n == 19 && g.k == 5 && g.NW == 12);
@@ -124,11 +124,8 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   const bool use_pair = pair_geom && w_fits && act_bytes != MNK_ACT_BITS7 &&
                         (pair_override >= 0 ? pair_override != 0 : N <= 32768);
   const bool rec = rec_planes && rec_meta;
-  // MNK_ROLLOUT_FORM=lane|pair|ws2|ws4 forces a kernel form (read per call: A/B timing, parity tests of every form)
-  const char* form = getenv("MNK_ROLLOUT_FORM");
-  int ws = 0;
-  if (form && !strcmp(form, "ws2")) ws = 2;
-  if (form && !strcmp(form, "ws4")) ws = 4;
+  // MNK_ROLLOUT_FORM=lane|pair|pairw|ws2|ws4 forces a kernel form (A/B timing, parity tests of every form)
+  const int ws = cfg.form == MNK_FORM_WS2 ? 2 : (cfg.form == MNK_FORM_WS4 ? 4 : 0);
   if (ws && act_bytes != MNK_ACT_BITS7 && mnk_rollout_ws_supported(g, act_bytes)) {
     mnk_launch_rollout_ws(g, ws, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,
                           rec ? rec_meta : nullptr, stats, act_log, act_bytes, stream);
@@ -138,8 +135,7 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   // enough to pay for the ~1 s of compilation: MNK_JIT=1 always, MNK_JIT=0 never, unset = from 2^20 env-steps per
   // launch (4 096 envs x 256 plies).  If the compile fails the generic kernel below still runs.
   if (!pair_geom) {
-    const char* jit_env = getenv("MNK_JIT");
-    const bool want = jit_env ? atoi(jit_env) != 0 : (N * (int64_t)T >= (1ll << 20));
+    const bool want = cfg.jit >= 0 ? cfg.jit != 0 : (N * (int64_t)T >= (1ll << 20));
     if (want) {
       if (hipFunction_t fn = mnk_jit_rollout_function(g, rec, act_bytes, rec && mnk_rollout_saddr_ok(g, N, T)))
         return mnk_jit_launch_rollout(fn, g, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,
@@ -149,8 +145,8 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   // two lanes per env: split by WORDS on the boards where that measured faster (us per 256 plies at 32 768 envs,
   // by directions / by words: 19x19 216 / 164, 15x15 155 / 135, 13x13 127 / 117; 9x9 86 / 98 stays split by
   // directions); MNK_ROLLOUT_FORM=pair|pairw forces one (pairw at any batch size)
-  const bool force_w = form && !strcmp(form, "pairw");
-  const bool force_d = form && !strcmp(form, "pair");
+  const bool force_w = cfg.form == MNK_FORM_PAIRW;
+  const bool force_d = cfg.form == MNK_FORM_PAIR;
   if (mnk_rollout_pairw_supported(g) && w_fits && act_bytes != MNK_ACT_BITS7 &&
       (force_w || (use_pair && !force_d && g.n >= 13))) {
     mnk_launch_rollout_pairw(g, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,

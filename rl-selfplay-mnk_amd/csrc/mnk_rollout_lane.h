@@ -34,6 +34,13 @@
 // (one 4-byte write, one s_barrier, one read per ply) and the record rows are split between the waves.  Move
 // selection and the state update are redundant.  Twice / four times the waves of the one-lane form: for batches
 // that leave SIMDs empty or alone with one wave, on boards whose scan dominates the ply (19x19).
+// FAST (a template flag of ply / pick, one-lane form): every lane of the wave holds a CONSISTENT game -- as many stones
+// on the board as plies counted, and fewer than C of them -- which is true of every state the env itself produces and
+// stays true ply after ply (a ply adds one stone and one count; a finished game restarts at 0 / 0).  Then a board
+// cannot be full when a ply begins, so the "no legal cell" branch (a compare and a scalar branch per ply) is gone;
+// and the ply counter is redundant -- C minus the number of legal cells -- so its increment, its reset select and
+// its store-back disappear from the loop (the draw test becomes "this was the last legal cell").  Poked states (stones
+// placed through env.boards, counts set by hand) make the wave take the general loop for that launch: same results.
 // SADDR (one-lane form only): the record stores address `uniform base + 32-bit lane offset` (global_store ... s[base])
 // instead of a 64-bit pointer per lane -- two address instructions fewer per ply; one launch may then write at
 // most 4 GiB of record rows (the launcher checks).
@@ -196,15 +203,18 @@ struct RolloutLane {
 
   // uniform legal cell from one u32 (oracle/philox.py pick_legal; selfplay/policy.py:18-29): the action, and
   // the cell's bit as a one-hot string
-  __device__ __forceinline__ int pick(uint32_t x, uint32_t (&hot)[NW]) const {
+  template <bool FAST = false>
+  __device__ __forceinline__ int pick(uint32_t x, uint32_t (&hot)[NW], uint32_t& nlegal) const {
     uint32_t legal[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) legal[w] = ~(cur[w] | oth[w]) & g.valid[w];
     const int nl = bs_popcount<NW>(legal);
+    nlegal = (uint32_t)nl;
     int n = nl;
     // full board (poked states only): any cell, like RandomPolicy's 1e-8 guard -- the r-th valid cell is cell r.
     // A wave-uniform branch that is practically never taken: one compare and one scalar branch per ply.
-    if (__builtin_amdgcn_ballot_w64(nl == 0) != 0) {
+    // FAST: a consistent game has a legal cell whenever a ply begins.
+    if (!FAST && __builtin_amdgcn_ballot_w64(nl == 0) != 0) {
 #pragma unroll
       for (int w = 0; w < NW; ++w) legal[w] = nl ? legal[w] : g.valid[w];
       n = nl ? nl : g.C;
@@ -216,9 +226,11 @@ struct RolloutLane {
 
   // field = position of this ply inside its group of four (= step & 3; a compile-time constant in
   // the unrolled main loop, so the log costs one shift-or per ply and one wide store per four)
+  template <bool FAST = false>
   __device__ __forceinline__ void ply(uint32_t x, int field) {
     uint32_t hot[NW];
-    const int a = pick(x, hot);
+    uint32_t nlegal;
+    const int a = pick<FAST>(x, hot, nlegal);
     if constexpr (ACT == 3) {
       q32 |= (uint32_t)a << (7 * field);
       if (field == 3) log_flush();
@@ -226,7 +238,7 @@ struct RolloutLane {
       quad |= (uint64_t)(uint32_t)a << (8 * ACT * field);
       if (field == 3) log_flush();
     }
-    ply_hot(a, hot);
+    ply_hot<FAST>(a, hot, nlegal);
   }
 
   // one ply with a known-good action (from an action log the sampler wrote)
@@ -241,15 +253,18 @@ struct RolloutLane {
     uint32_t hot[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) hot[w] = (w == wsel) ? one : 0u;
-    ply_hot(a, hot);
+    ply_hot<false>(a, hot);
   }
 
   // env/torch_vector_mnk_env.py:60-84 for the mover, then env.reset(nonzero(done)) :34-44
-  __device__ __forceinline__ void ply_hot(int a, const uint32_t (&hot)[NW]) {
+  // FAST (see the top of this file): `moves` is not maintained -- the board is full after this ply iff the move took
+  // the last legal cell (nlegal == 1); finish_fast() restores the counter from the board when the loop is over
+  template <bool FAST = false>
+  __device__ __forceinline__ void ply_hot(int a, const uint32_t (&hot)[NW], uint32_t nlegal = 0) {
     if (RECORD) store_record();
 #pragma unroll
     for (int w = 0; w < NW; ++w) cur[w] |= hot[w];                    // :68
-    ++moves;                                                          // :69
+    if (!FAST) ++moves;                                               // :69
     uint32_t win;                                                     // :71
     if constexpr (PAIR) {
       // role 0 scans columns and rows, role 1 diagonals and anti-diagonals; paired so that the word parts of
@@ -281,7 +296,7 @@ struct RolloutLane {
     } else {
       win = mnk_plane_wins<NW, CN, CK>(g, cur) ? 1u : 0u;
     }
-    const uint32_t done = win | (moves >= (uint32_t)g.C ? 1u : 0u);   // :72-73
+    const uint32_t done = win | ((FAST ? nlegal == 1u : moves >= (uint32_t)g.C) ? 1u : 0u);   // :72-73
     if (RECORD) {
       const uint32_t mword = (uint32_t)a | (win << MNK_REC_REWARD_SHIFT) | (done << MNK_REC_DONE_BIT) | (side << MNK_REC_SIDE_BIT);
       if constexpr (OFF32) {
@@ -303,9 +318,49 @@ struct RolloutLane {
       oth[w] = done ? 0u : c;
     }
     side = done ? 0u : (side ^ 1u);
-    moves = done ? 0u : moves;
+    if (!FAST) moves = done ? 0u : moves;
+  }
+
+  // is this lane's game consistent (stones on the board == plies counted < C)?  -> the wave may take the FAST loop
+  __device__ __forceinline__ bool consistent() const {
+    uint32_t occ[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) occ[w] = cur[w] | oth[w];
+    return (uint32_t)bs_popcount<NW>(occ) == moves && moves < (uint32_t)g.C;
+  }
+
+  // after a FAST loop: the ply counter of a consistent game is its stone count
+  __device__ __forceinline__ void finish_fast() {
+    uint32_t occ[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) occ[w] = cur[w] | oth[w];
+    moves = (uint32_t)bs_popcount<NW>(occ);
   }
 };
+
+// the T plies of one lane: head (finish the Philox block the previous launch stopped in), groups of four plies on
+// one Philox block each with the word picked at compile time, tail
+template <bool FAST, typename Lane>
+__device__ __forceinline__ void rollout_plies(Lane& L, int T, uint64_t seed, uint64_t step0, uint64_t env) {
+  int t = 0;
+  uint64_t step = step0;
+  if (step & 3) {
+    const Philox4 blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
+    for (; t < T && (step & 3); ++t, ++step)
+      L.template ply<FAST>(philox_word(blk, (uint32_t)(step & 3)), (int)(step & 3));
+  }
+  for (; t + 4 <= T; t += 4, step += 4) {
+    const Philox4 blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
+    L.template ply<FAST>(blk.v[0], 0);
+    L.template ply<FAST>(blk.v[1], 1);
+    L.template ply<FAST>(blk.v[2], 2);
+    L.template ply<FAST>(blk.v[3], 3);
+  }
+  if (t < T) {
+    const Philox4 blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
+    for (uint32_t j = 0; t < T; ++t, ++j) L.template ply<FAST>(philox_word(blk, j), (int)j);
+  }
+}
 
 // the one-lane kernel's body: one wave of 64 envs per workgroup of 64 threads
 template <int NW, int CN, int CK, bool RECORD, int ACT, bool SADDR = false>
@@ -323,22 +378,18 @@ __device__ __forceinline__ void rollout_random_body(const MnkGeom& g, uint64_t* 
     RolloutLane<NW, CN, CK, RECORD, ACT, false, 1, SADDR> L(g, N, i, rec_planes, rec_meta, act_log);
     L.load(planes, meta, i);
     const uint64_t env = (uint64_t)(env_id0 + i);
-    int t = 0;
-    uint64_t step = step0;
-    if (step & 3) {  // head: finish the Philox block the previous launch stopped in
-      const Philox4 blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
-      for (; t < T && (step & 3); ++t, ++step) L.ply(philox_word(blk, (uint32_t)(step & 3)), (int)(step & 3));
-    }
-    for (; t + 4 <= T; t += 4, step += 4) {
-      const Philox4 blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
-      L.ply(blk.v[0], 0);
-      L.ply(blk.v[1], 1);
-      L.ply(blk.v[2], 2);
-      L.ply(blk.v[3], 3);
-    }
-    if (t < T) {
-      const Philox4 blk = mnk_rng_block(seed, env, step >> 2, MNK_STREAM_MOVE);
-      for (uint32_t j = 0; t < T; ++t, ++j) L.ply(philox_word(blk, j), (int)j);
+    // every lane of this wave in a consistent game (any state the env produced itself): the FAST loop; a wave that
+    // holds a poked state plays this launch on the general loop.  Same records either way.
+    // Only where it measured faster (same-box A/B, us per 256 plies at 65 536 envs: 3x3x3 59.1 -> 53.4, 9x9x5 88.1 ->
+    // 82.7, 7x9x7 106.9 -> 100.8, 13x13x5 143 -> 135.8): there the kernel is bound by its instruction count.  Where
+    // the HBM write rate is the bound the second loop cost more than it saved (12x12x5 138 -> 147, 15x15x5 205 -> 218,
+    // 19x19x5 267 -> 305: the compiler's schedule of the record stores changed), so those keep the one general loop.
+    constexpr bool TRY_FAST = NW <= 3 || (NW == 6 && CN == 13);
+    if (TRY_FAST && __builtin_amdgcn_ballot_w64(!L.consistent()) == 0) {
+      rollout_plies<true>(L, T, seed, step0, env);
+      L.finish_fast();
+    } else {
+      rollout_plies<false>(L, T, seed, step0, env);
     }
     L.log_finish(T);  // T not a multiple of 4: the last word is partly filled
     L.store(planes, meta, i);

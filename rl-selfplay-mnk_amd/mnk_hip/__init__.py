@@ -33,6 +33,7 @@ _vp, _i, _i64, _u64, _u32, _f = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, 
 # (tests/test_abi.py parses the header and compares).
 SIGNATURES = {
     "mnk_abi_version": [],
+    "mnk_reload_config": [],
     "mnk_state_words": [_i, _i],
     "mnk_record_words": [_i, _i],
     "mnk_geometry_supported": [_i, _i, _i],
@@ -93,7 +94,12 @@ def load():
         )
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError here = header / library mismatch
+        try:
+            fn = getattr(lib, name)  # AttributeError here = header / library mismatch
+        except AttributeError:
+            if os.environ.get("MNK_HIP_LIB"):  # an older build loaded for an A/B run: entry points added since are absent
+                continue
+            raise
         fn.argtypes = argtypes
         if name in ("mnk_last_launch_error", "mnk_comm_last_error", "mnk_jit_last_error"):
             fn.restype = ctypes.c_char_p
@@ -153,6 +159,12 @@ def obs_dtype_code(dtype) -> int:
 def obs_code(t) -> int:
     """MNK_OBS_* code of an observation tensor (None -> F32: the pointer is NULL and the code is not looked at)"""
     return OBS_F32 if t is None else obs_dtype_code(t.dtype)
+
+
+def reload_config() -> None:
+    """The library reads its developer knobs (MNK_ROLLOUT_PAIR / _FORM / _SADDR, MNK_JIT, MNK_EMIT_ENVS / _THREADS) from
+    the environment once; call this after changing ``os.environ`` to make it read them again."""
+    call("mnk_reload_config")
 
 
 def state_words(m, n):

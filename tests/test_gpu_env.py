@@ -169,7 +169,18 @@ def _force_form(param):
         os.environ["MNK_ROLLOUT_FORM"] = "ws2" if param.startswith("two") else "ws4"
     elif param.startswith("two lanes"):  # split by scan directions, or by board words (19x19 / 15x15 only)
         os.environ["MNK_ROLLOUT_FORM"] = "pairw" if "words" in param else "pair"
+    _reload_knobs()
     return saved
+
+
+def _reload_knobs():
+    """the library reads its environment knobs once; tell it the environment has changed"""
+    import __graft_entry__ as entry
+
+    entry._ensure_path()
+    import mnk_hip
+
+    mnk_hip.reload_config()
 
 
 def _restore_form(saved):
@@ -178,6 +189,7 @@ def _restore_form(saved):
             os.environ.pop(key, None)
         else:
             os.environ[key] = val
+    _reload_knobs()
 
 
 @pytest.fixture(params=["one lane per env", "two lanes per env", "two lanes per env, words split"])
@@ -260,6 +272,63 @@ def test_rollout_matches_oracle(hip, m, n, k, nenv, chunks, lanes_per_env):
         assert np.array_equal(pack_boards(env.boards.cpu().numpy(), m, n), pack_boards(ora.boards.numpy(), m, n))
         assert np.array_equal(env.current_player.cpu().numpy(), ora.current_player.numpy())
         assert np.array_equal(env.move_counts.cpu().numpy(), ora.move_counts.numpy())
+
+
+@pytest.mark.parametrize("m,n,k", [(9, 9, 5), (3, 3, 3), (13, 13, 5), (4, 6, 3), (15, 15, 5)])
+def test_rollout_on_poked_states_takes_the_general_loop(hip, m, n, k):
+    """The one-lane rollout kernel plays a wave whose games are all CONSISTENT (stones on the board == plies counted
+    < C: every state the env itself produces) on a loop without the full-board branch and without a ply counter
+    (mnk_rollout_lane.h, FAST); a wave that holds a poked state plays the general loop.  Here 256 envs = four waves:
+    the first two untouched, the other two carrying hand-made states -- a full board with the counter at 0 (every ply
+    lands on an occupied cell until the counter reaches C), a counter ahead of / behind the stones, two stones on one
+    cell, a finished game left un-reset (counter == C), a position one ply short of a draw -- and everything equals
+    the oracle, records, statistics and final state, over several launches."""
+    nenv, c = 256, m * n
+    env = hip.Env(m, n, k, nenv, device=DEV)
+    ora = OracleVectorEnv(m, n, k, nenv)
+    # mid-game positions everywhere first (both sides identical), then the pokes
+    hip.Rollout(env, seed=9).run(max(4, c // 3) - max(4, c // 3) % 4, record=False)
+    random_rollout(ora, seed=9, step0=0, steps=max(4, c // 3) - max(4, c // 3) % 4)
+    assert np.array_equal(pack_boards(env.boards.cpu().numpy(), m, n), pack_boards(ora.boards.numpy(), m, n))
+    rng = np.random.default_rng(5)
+
+    def poke(i, boards, side, count):
+        for target in (env, ora):
+            if boards is not None:
+                target.boards[i] = torch.from_numpy(boards)
+            target.current_player[i] = side
+            target.move_counts[i] = count
+
+    full = np.zeros((2, m, n), dtype=np.float32)
+    full[0].reshape(-1)[0::2] = 1.0
+    full[1].reshape(-1)[1::2] = 1.0           # a full board (it may or may not hold a line: the scan decides)
+    poke(130, full, 0, 0)                     # full, counter 0: occupied-cell plies until the counter reaches C
+    poke(131, full, 1, c - 2)                 # full, two plies from the draw by the counter
+    poke(140, None, 0, 3 * c)                 # counter far ahead of the stones: "draw" at the next ply without a win
+    poke(141, None, 1, 0)                     # counter behind the stones
+    both = np.zeros((2, m, n), dtype=np.float32)
+    both[:, 0, 0] = 1.0                       # the same cell taken by both sides (an occupied-cell overwrite happened)
+    both[0, 1, 1] = 1.0
+    poke(200, both, 0, 3)
+    sparse = (rng.random((2, m, n)) < 0.15).astype(np.float32)
+    sparse[1] *= 1.0 - sparse[0]
+    poke(201, sparse, 1, c)                   # a finished game that was never reset: counter == C already
+    poke(255, sparse, 0, int(sparse.sum()))   # consistent by construction, in a wave that is not
+    assert torch.equal(env.move_counts.cpu(), ora.move_counts)
+    roll = hip.Rollout(env, seed=77, env_id0=1000)
+    total = np.zeros(5, dtype=np.int64)
+    step0 = 0
+    for t in (8, c + 4, 20, 13):
+        rec = roll.run(t)
+        planes, meta, stats = random_rollout(ora, seed=77, step0=step0, steps=t, env_id0=1000)
+        total += stats
+        step0 += t
+        assert np.array_equal(rec.planes.cpu().numpy().view(np.uint64), planes), t
+        assert np.array_equal(rec.meta.cpu().numpy().view(np.uint32), meta), t
+        assert np.array_equal(roll.stats.cpu().numpy(), total), t
+        assert np.array_equal(pack_boards(env.boards.cpu().numpy(), m, n), pack_boards(ora.boards.numpy(), m, n)), t
+        assert np.array_equal(env.current_player.cpu().numpy(), ora.current_player.numpy()), t
+        assert np.array_equal(env.move_counts.cpu().numpy(), ora.move_counts.numpy()), t
 
 
 def test_rollout_is_independent_of_sharding(hip):
@@ -436,6 +505,7 @@ def test_generic_geometries_match_oracle(hip, m, n, k):
     try:
         for jit in ("0", "1"):
             os.environ["MNK_JIT"] = jit
+            _reload_knobs()
             env = hip.Env(m, n, k, nenv, device=DEV)
             roll = hip.Rollout(env, seed=m * 1000 + n * 10 + k)
             rec = roll.run(steps)
@@ -457,6 +527,7 @@ def test_generic_geometries_match_oracle(hip, m, n, k):
             os.environ.pop("MNK_JIT", None)
         else:
             os.environ["MNK_JIT"] = saved
+        _reload_knobs()
     acts = torch.from_numpy(np.random.default_rng(k).integers(-m * n, m * n, nenv))
     o1, r1, d1 = env.step(acts.to(DEV))
     o2, r2, d2 = ora.step(acts)

@@ -21,6 +21,9 @@ def set_form(name):
         os.environ["MNK_ROLLOUT_FORM"] = form
     else:
         os.environ.pop("MNK_ROLLOUT_FORM", None)
+    import mnk_hip
+
+    mnk_hip.reload_config()  # the library reads its environment knobs once
 
 
 def run(board, nenv, chunk=256, reps=40, record=True, log=False):
