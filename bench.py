@@ -8,10 +8,12 @@ env -- per ply: uniform legal move (RandomPolicy), place stone, 4-direction win 
 restart of finished games, packed record written to HBM.  ``value`` is env-steps (plies x envs)
 per second.  With --gpus N > 1 the env axis is sharded (65 536 envs per
 rank, global env ids key the RNG) and every chunk is all-gathered over RCCL on a side stream
-while the next chunk runs -- by default as the action log alone (7 bits per action at 9x9 = 0.875 B
-per env-step; every rank holds every shard's replay state, gathered once before the first chunk, and
-mnk_replay_actions rebuilds full records from state + log), with --gather actions+state as a
-self-contained message (chunk-start state + log), with --gather records as the 28 B packed records.
+while the next chunk runs -- by default as a keyframed action log: 7 bits per action at 9x9 (0.875 B
+per env-step) plus, in every 8th chunk's message (--keyframe), the chunk-start state (36 B per env):
+0.893 B per env-step; mnk_replay_actions rebuilds any chunk's full records on demand from the last
+keyframe + the logs since.  --keyframe 1 makes every message self-contained, --keyframe 0 sends the
+state once before the first chunk (receivers must then replay every chunk to keep it current);
+--gather records all-gathers the 28 B packed records themselves.
 
     python bench.py                       # 1 GPU, defaults finish in well under a minute
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -41,7 +43,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 # (FETCH_SIZE x 1024 x 2 [gfx950 correction] + WRITE_SIZE x 1024), keyed by (board, envs/GPU, chunk).
 # bench.py cannot run rocprofv3 on itself; configurations without a committed profile report null.
 PMC_TRAFFIC = {
-    ("9x9x5", 65536, 256): (474.67e6, "profiles/r02_rollout_9x9x5.md"),
+    ("9x9x5", 65536, 256): (474.71e6, "profiles/r03_rollout_9x9x5.md"),
     ("19x19x5", 32768, 256): (845.85e6, "profiles/r02_rollout_19x19x5_32768.md"),   # two lanes per env, words split
     ("12x12x5", 65536, 256): (745.25e6, "profiles/r02_rollout_12x12x5_jit.md"),     # run-time specialised kernel
 }
@@ -71,9 +73,13 @@ def parse():
                          "with a small conv policy as agent and an opponent pool (agent-steps/s, NN time dominates)")
     ap.add_argument("--backend", default="nccl", help="process-group backend; nccl = RCCL.  gloo is for rehearsing "
                     "the multi-rank path on a one-GPU box (all ranks then share device 0)")
-    ap.add_argument("--gather", choices=("actions", "actions+state", "records", "none"), default="actions",
-                    help="what ranks all-gather per chunk when --gpus > 1 (ignored on one GPU): the action log alone "
-                         "(receivers keep the replay state), the log with the chunk-start state, or the packed records")
+    ap.add_argument("--gather", choices=("actions", "records", "none"), default="actions",
+                    help="what ranks all-gather per chunk when --gpus > 1 (ignored on one GPU): the action log (see "
+                         "--keyframe) or the packed records")
+    ap.add_argument("--keyframe", type=int, default=8,
+                    help="--gather actions: every K-th chunk's message also carries the chunk-start state (a keyframe), so "
+                         "any chunk's records can be rebuilt on demand from at most K messages; 1 = every message is "
+                         "self-contained, 0 = the state is gathered once before the first chunk and never again")
     ap.add_argument("--allow-fallback", action="store_true",
                     help="if the C-ABI RCCL communicator (mnk_comm_*) cannot be created, run the same all-gather through "
                          "torch.distributed instead of exiting non-zero")
@@ -306,10 +312,27 @@ def write_ceiling_GBps(dev, nenv, chunk, rows, seconds=0.05):
 
 
 def gpu_identity(dev):
+    """Identity of the device the numbers were taken on: torch's device properties plus what `rocminfo` (a child
+    process) says about the first gfx950 agent -- marketing name (empty on this pool's image), max clock, CUs."""
+    import re
+    import subprocess
+
     p = torch.cuda.get_device_properties(dev)
-    return {"name": p.name, "arch": getattr(p, "gcnArchName", None), "compute_units": p.multi_processor_count,
-            "clock_MHz": getattr(p, "clock_rate", 0) / 1e3 or None, "memory_GiB": round(p.total_memory / 2 ** 30, 1),
-            "hip": torch.version.hip}
+    out = {"name": p.name, "arch": getattr(p, "gcnArchName", None), "compute_units": p.multi_processor_count,
+           "memory_GiB": round(p.total_memory / 2 ** 30, 1), "hip": torch.version.hip, "rocminfo": None}
+    try:
+        text = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=20).stdout
+        for block in text.split("*******")[1:]:
+            if re.search(r"^\s*Name:\s+gfx950", block, flags=re.M):
+                def field(label):
+                    m = re.search(r"^[ \t]*" + label + r":[ \t]*(.*?)[ \t]*$", block, flags=re.M)
+                    return m.group(1) if m else None
+                out["rocminfo"] = {"name": field("Name"), "marketing_name": field("Marketing Name"),
+                                   "max_clock_MHz": field(r"Max Clock Freq\. \(MHz\)"), "compute_units": field("Compute Unit")}
+                break
+    except Exception as e:  # noqa: BLE001 -- identity is best effort
+        out["rocminfo"] = f"unavailable: {e}"
+    return out
 
 
 def selfplay_object(m, n, k, nenv, seed, dev, steps=64):
@@ -620,11 +643,29 @@ def main():
     env.reset()
     roll = RandomRollout(env, seed=args.seed, env_id0=rank * nenv)
     mode = args.gather if world > 1 else "none"
-    logging = mode in ("actions", "actions+state")
+    logging = mode == "actions"
     if logging:  # a group of the log holds plies 4q..4q+3: chunks (and so the warm-up) end on multiples of 4
         chunk = args.chunk = max(4, chunk - chunk % 4)
-    bufs = [roll.alloc(chunk, log_actions=logging, with_state=(mode == "actions+state")) for _ in range(2)]
-    gathered = side = exchange = start_state = None
+    keyframe = max(0, args.keyframe)
+    # two slots (a chunk is gathered while the next one computes); with a log, per slot a message with the chunk-start
+    # state (keyframes) and one without, sharing the slot's record buffers
+    bufs = [roll.alloc(chunk, log_actions=logging, with_state=True) for _ in range(2)]
+    bufs_log = None
+    if logging and keyframe != 1:
+        from selfplay.random_rollout import _msg_views, _msg_words
+
+        bufs_log = []
+        for b in bufs:
+            rec = type(b)(planes=b.planes, meta=b.meta)
+            rec.fmt = b.fmt
+            rec.msg = torch.zeros(_msg_words(env.words, nenv, chunk, b.fmt, False), dtype=torch.int64, device=dev)
+            rec.planes0, rec.act, rec.meta0 = _msg_views(rec.msg, env.words, nenv, chunk, b.fmt, False)
+            bufs_log.append(rec)
+    gathered = gathered_log = side = exchange = start_state = None
+    chunk_no = [0]  # chunks played so far (keyframes are counted from the first chunk of the run)
+
+    def is_keyframe(c):
+        return keyframe == 1 or (keyframe > 1 and c % keyframe == 0)
     if mode != "none":
         side = torch.cuda.Stream(dev)
         if args.backend == "nccl":  # the collective goes through the C ABI (mnk_allgather_records), RCCL over xGMI
@@ -654,7 +695,10 @@ def main():
                          torch.empty((world,) + tuple(b.meta.shape), dtype=torch.int32, device=dev)) for b in bufs]
         else:
             gathered = [GatheredLogs.empty(world, env.words, nenv, chunk, env.max_moves, dev, fmt=bufs[0].fmt,
-                                           with_state=(mode == "actions+state")) for _ in bufs]
+                                           with_state=True) for _ in bufs]
+            if bufs_log is not None:
+                gathered_log = [GatheredLogs.empty(world, 0, nenv, chunk, env.max_moves, dev, fmt=bufs[0].fmt,
+                                                   with_state=False) for _ in bufs]
     main_stream = torch.cuda.current_stream(dev)
     gather_done = [None, None]
     kernel_events = []  # (start, end) HIP events around every rollout launch of the timed region
@@ -671,7 +715,9 @@ def main():
             slot = c & 1
             if gather_done[slot] is not None:
                 main_stream.wait_event(gather_done[slot])  # the buffer is free again
-            out = bufs[slot]
+            key = not logging or is_keyframe(chunk_no[0])
+            chunk_no[0] += 1
+            out = bufs[slot] if key else bufs_log[slot]
             assert t == chunk  # a bench step is a whole chunk
             # kernel time: with an exchange step in the loop every launch is bracketed by its own pair of HIP
             # events (the stream also waits for gathers); on one GPU two events around the whole timed region
@@ -693,7 +739,7 @@ def main():
                         gs = torch.cuda.Event(enable_timing=True)
                         gs.record(side)
                     if logging:
-                        gather_action_logs(out, out=gathered[slot], exchange=exchange, stream=side)
+                        gather_action_logs(out, out=(gathered if key else gathered_log)[slot], exchange=exchange, stream=side)
                     else:
                         gp, gm = gathered[slot]
                         if exchange is not None:
@@ -718,9 +764,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    if mode == "actions":
-        # the log travels alone: every rank takes every shard's start state once (36 B per env), outside the timed
-        # region, and from then on advances it by replaying the logs (replay_shard(..., state=start_state))
+    if logging and keyframe == 0:
+        # the log travels alone from the first chunk on: every rank takes every shard's start state once (36 B per
+        # env), outside the timed region; keeping it current is the receivers' job (replay_shard(..., state=...))
         start_state = gather_start_state(env, exchange=exchange, stream=main_stream)
         torch.cuda.synchronize(dev)
     run_steps(args.settle * chunk)
@@ -766,7 +812,7 @@ def main():
         def run_compute_only(total):
             done = 0
             while done < total:
-                roll.run(chunk, out=bufs[(done // chunk) & 1])
+                roll.run(chunk, out=(bufs_log or bufs)[(done // chunk) & 1])
                 done += chunk
 
         barrier()
@@ -835,7 +881,10 @@ def main():
     }
     if mode != "none":
         if logging:
-            msg_bytes = bufs[0].msg.numel() * 8
+            key_bytes = bufs[0].msg.numel() * 8
+            log_bytes = bufs_log[0].msg.numel() * 8 if bufs_log is not None else key_bytes
+            share = 1.0 if keyframe == 1 else (0.0 if keyframe == 0 else 1.0 / keyframe)
+            msg_bytes = share * key_bytes + (1.0 - share) * log_bytes  # average per chunk
         else:
             msg_bytes = bufs[0].planes.numel() * 8 + bufs[0].meta.numel() * 4
         mean_ms = sum(gather_ms) / max(len(gather_ms), 1)
@@ -846,10 +895,14 @@ def main():
         compute_ms = world * nenv * plies / compute_only * 1e3 / args.steps
         exposed_ms = max(0.0, step_ms - compute_ms)
         out["exchange"] = {
-            "what": {"actions": "the action log alone (7-bit stream up to 128 cells, else 1-2 bytes per action); every rank "
-                                "holds every shard's replay state, gathered once before the first chunk",
-                     "actions+state": "chunk-start planes | action log | chunk-start meta (a self-contained message)",
+            "what": {"actions": "the action log (7-bit stream up to 128 cells, else 1-2 bytes per action)" +
+                                (f"; every {keyframe}th chunk's message also carries the chunk-start state (keyframe), "
+                                 "records of any chunk are rebuilt on demand from the last keyframe + the logs since"
+                                 if keyframe > 1 else "; every message carries the chunk-start state (self-contained)"
+                                 if keyframe == 1 else "; the state was gathered once before the first chunk: receivers "
+                                 "must replay every chunk to keep it current"),
                      "records": "packed records (rows + meta word per ply)"}[mode],
+            "keyframe_every_chunks": keyframe if logging else None,
             "start_state_bytes_per_rank": start_state.msg.shape[1] * 8 if start_state is not None else 0,
             "transport": "mnk_allgather_records (C ABI, RCCL)" if exchange is not None
                          else f"torch.distributed {args.backend}" + (" (FALLBACK: the C-ABI communicator failed)"

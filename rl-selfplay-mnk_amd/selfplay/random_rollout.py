@@ -294,16 +294,18 @@ def replay_shard(logs: GatheredLogs, shard: int, m: int, n: int, k: int, err: Op
     """Rebuilds shard ``shard``'s full packed records from its chunk-start state + action log
     (``mnk_replay_actions``, one launch); bit-identical to what the owning rank recorded.
     The state comes from the message itself (self-contained messages: a copy is advanced, ``scratch`` = optional
-    ``(planes int64 [2, W, N], meta int32 [N])`` buffers for it) or from ``state`` (log-only messages: the shard's
-    entry of the ``ReplayState`` is advanced IN PLACE, so every chunk must be replayed, in order, exactly once;
-    ``record=False`` only advances the state)."""
+    ``(planes int64 [2, W, N], meta int32 [N])`` buffers for it) or from ``state`` -- a ``ReplayState`` (its entry for
+    ``shard``) or a ``(planes [2, W, N], meta [N])`` pair -- which is advanced IN PLACE: for log-only messages, where
+    every chunk must be replayed in order exactly once (``record=False`` only advances the state)."""
     act = logs.act[shard]
     t, nenv = logs.steps, act.shape[1]
     assert act.shape[0] == (action_log_words(logs.fmt, t) if logs.fmt != ACT_U16 else (t + 3) // 4), \
         "GatheredLogs.steps does not match the packed log"
     dev = act.device
-    if state is not None:
+    if isinstance(state, ReplayState):
         planes, meta = state.planes[shard], state.meta[shard]
+    elif state is not None:
+        planes, meta = state
     elif logs.planes0 is None:
         raise ValueError("log-only messages need the receiver's ReplayState (gather_start_state)")
     elif scratch is not None:
@@ -325,6 +327,53 @@ def replay_shard(logs: GatheredLogs, shard: int, m: int, n: int, k: int, err: Op
                      mnk_hip.ptr(act), logs.fmt, mnk_hip.ptr(out.planes if out is not None else None),
                      mnk_hip.ptr(out.meta if out is not None else None), mnk_hip.ptr(err), mnk_hip.stream_ptr(dev))
     return out
+
+
+class KeyframedLogs:
+    """The receiving side of a KEYFRAMED log stream: every K-th chunk's message carries the chunk-start state (a
+    keyframe), the chunks in between carry the log alone.  The wire then costs 0.875 + 36 / (K * T) bytes per env-step
+    at 9x9 (0.893 at K = 8, T = 256) and nobody has to keep replaying: the records of any chunk since the last keyframe
+    are rebuilt ON DEMAND -- state-only replays of the chunks before it (no record stores: ~60 us per 256 plies x 65 536
+    envs), then one recording replay.  ``push`` COPIES what it is given (the gather buffers are reused)."""
+
+    def __init__(self, m: int, n: int, k: int):
+        self.geom = (m, n, k)
+        self.key: Optional[GatheredLogs] = None
+        self.tail = []  # log-only GatheredLogs since the keyframe
+
+    @staticmethod
+    def _copy(logs: GatheredLogs) -> GatheredLogs:
+        msg = logs.msg.clone()
+        world = msg.shape[0]
+        with_state = logs.planes0 is not None
+        w = logs.planes0.shape[2] if with_state else 0
+        nenv = logs.act.shape[-1]
+        planes0, act, meta0 = _msg_views(msg, w, nenv, logs.steps, logs.fmt, with_state)
+        assert act.shape == logs.act.shape and world == logs.act.shape[0]
+        return GatheredLogs(planes0=planes0, meta0=meta0, act=act, steps=logs.steps, msg=msg, fmt=logs.fmt)
+
+    def push(self, logs: GatheredLogs) -> None:
+        if logs.planes0 is not None:
+            self.key, self.tail = self._copy(logs), []
+        else:
+            if self.key is None:
+                raise ValueError("a log-only message before the first keyframe")
+            self.tail.append(self._copy(logs))
+
+    def chunks(self) -> int:
+        """chunks held: the keyframe chunk plus the log-only ones after it"""
+        return 0 if self.key is None else 1 + len(self.tail)
+
+    def rebuild(self, shard: int, j: int, err: Optional[torch.Tensor] = None) -> RolloutRecords:
+        """Records of chunk ``j`` since the keyframe (0 = the keyframe's own chunk) of shard ``shard``."""
+        if not 0 <= j < self.chunks():
+            raise IndexError(f"chunk {j} of {self.chunks()} held since the last keyframe")
+        m, n, k = self.geom
+        state = (self.key.planes0[shard].clone(), self.key.meta0[shard].clone())
+        seq = [self.key] + self.tail
+        for i in range(j):
+            replay_shard(seq[i], shard, m, n, k, err=err, state=state, record=False)
+        return replay_shard(seq[j], shard, m, n, k, err=err, state=state)
 
 
 def gather_records(rec: RolloutRecords, group=None) -> RolloutRecords:

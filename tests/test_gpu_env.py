@@ -451,6 +451,38 @@ def test_action_log_replay_rebuilds_the_records(hip, m, n, k, nenv, steps, lane_
         hip.Rollout(hip.Env(13, 13, 5, 4, device=DEV)).alloc(8, log_actions=ACT_BITS7)  # 169 cells do not fit 7 bits
 
 
+@pytest.mark.parametrize("m,n,k,nenv", [(9, 9, 5, 300), (19, 19, 5, 70)])
+def test_keyframed_log_stream_rebuilds_any_chunk_on_demand(hip, m, n, k, nenv):
+    """The default exchange of the sharded rollout: every K-th chunk's message carries the chunk-start state (a
+    keyframe), the others the log alone.  ``KeyframedLogs`` on the receiving side rebuilds the records of ANY chunk
+    held since the last keyframe -- state-only replays up to it, then a recording one -- bit-identical to what the
+    sender recorded, and a new keyframe drops the history before it."""
+    from selfplay.random_rollout import GatheredLogs, KeyframedLogs
+
+    every, chunk = 3, 20
+    env = hip.Env(m, n, k, nenv, device=DEV)
+    roll = hip.Rollout(env, seed=31, env_id0=500)
+    history = KeyframedLogs(m, n, k)
+    with pytest.raises(ValueError):
+        history.push(GatheredLogs(planes0=None, meta0=None, act=torch.zeros((1, 1, nenv), dtype=torch.int32, device=DEV), steps=4))
+    sent = []
+    for c in range(8):
+        key = c % every == 0
+        rec = roll.alloc(chunk, log_actions=True, with_state=key)
+        roll.run(chunk, out=rec)
+        logs = GatheredLogs.empty(1, env.words if key else 0, nenv, chunk, m * n, DEV, fmt=rec.fmt, with_state=key)
+        logs.msg.copy_(rec.msg.unsqueeze(0))   # what a one-rank all-gather delivers
+        history.push(logs)
+        logs.msg.zero_()                        # the gather buffer is reused: the history holds its own copy
+        sent = [rec] if key else sent + [rec]
+        assert history.chunks() == len(sent) == c % every + 1
+        for j, want in enumerate(sent):
+            got = history.rebuild(0, j)
+            assert torch.equal(got.planes, want.planes) and torch.equal(got.meta, want.meta), (c, j)
+    with pytest.raises(IndexError):
+        history.rebuild(0, history.chunks())
+
+
 def test_action_log_needs_aligned_chunks(hip):
     env = hip.Env(3, 3, 3, 8, device=DEV)
     roll = hip.Rollout(env, seed=1)
