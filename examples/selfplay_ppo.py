@@ -1,6 +1,8 @@
-"""Self-play PPO on the HIP env with the drop-in pieces (wrapper, packed rollout buffer, opponent pool,
-device-side episode statistics, validation) -- the structure of the reference's train.py / alg/ppo.py loop,
-with a small MLP policy so it runs in seconds.
+"""Self-play PPO on the HIP env with the drop-in pieces (wrapper, packed rollout buffer as the SINK of the fused step,
+opponent pool, device-side episode statistics, validation) -- the structure of the reference's train.py / alg/ppo.py
+loop, with a small MLP policy so it runs in seconds.  ``wrap.attach_sink(buf)`` makes every ``wrap.step`` write the
+packed canonical planes of the next observation into row t+1 of the buffer and rewards / terminated into row t, so
+``buf.add`` copies only actions, values and log-probabilities.
 
     python examples/selfplay_ppo.py --board 3x3x3 --envs 2048 --iters 40
 """
@@ -58,20 +60,22 @@ def main():
     wrap.set_opponent(RandomPolicy(cells))
     pool = OpponentPool(max_size=8)
     buf = PackedRolloutBuffer(args.steps, args.envs, m, n, device=dev)
+    wrap.attach_sink(buf)  # the step kernels write straight into the buffer's rows
     obs, _ = wrap.reset()
+    packed = buf.row(0)["packed"]  # where reset() put the planes of the first observation
     for it in range(args.iters):
         if it % 5 == 4:
             pool.add_opponent(NNPolicy(copy.deepcopy(net)))
             wrap.set_opponent(pool.get_random_opponent())
             net.train()
-        for _ in range(args.steps):
-            packed = wrap.packed_obs()
+        for t in range(args.steps):
             with torch.no_grad():
                 dist, values = net(obs["observation"], obs["action_mask"])
                 actions = dist.sample()
                 logp = dist.log_prob(actions)
             obs, rewards, term, trunc, _ = wrap.step(actions)
             buf.add(packed, actions, rewards, values, logp, term | trunc)
+            packed = buf.row(t + 1)["packed"]  # the step wrote the next observation's planes here (spill row at the end)
         with torch.no_grad():
             _, last = net(obs["observation"], obs["action_mask"])
         buf.compute_advantages_and_returns(last.reshape(-1), 0.99, 0.95)

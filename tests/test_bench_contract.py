@@ -1,4 +1,4 @@
-"""CPU: the committed bench lines (profiles/r02_bench_*.json, printed by bench.py on the MI355X) carry every field
+"""CPU: the committed bench lines (profiles/r0N_bench_*.json, printed by bench.py on the MI355X) carry every field
 the driver's contract names, with consistent arithmetic -- a regression guard for bench.py's JSON."""
 import json
 import os
@@ -13,8 +13,9 @@ def _line(name):
         return json.loads(f.read().strip().splitlines()[-1])
 
 
-def test_one_gpu_line_has_the_contract_fields():
-    d = _line("r02_bench_line.json")
+@pytest.mark.parametrize("name", ["r02_bench_line.json", "r03_bench_line.json"])
+def test_one_gpu_line_has_the_contract_fields(name):
+    d = _line(name)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -48,3 +49,43 @@ def test_two_rank_rehearsal_line_describes_the_exchange():
                 "recv_GBps_per_rank", "per_link_GBps", "compute_ms_per_chunk", "exposed_ms_per_chunk", "overlap_fraction"):
         assert key in x, key
     assert x["bytes_per_env_step"] == pytest.approx(1.140625)  # 36 B state per 256 plies + 1 B per action + meta
+
+
+def test_round3_line_names_the_device_the_variant_and_the_ceiling():
+    """Round 3: GPU identity, the measured write ceiling next to the roofline, the one-launch
+    API path with its launch floor, the kernel variant the multi-GPU runs use, the env side of config 3, and the
+    exchange mode / kernel variant / transport at the top level of the line."""
+    d = _line("r03_bench_line.json")
+    assert d["gather"] == "none" and d["kernel_variant"].startswith("records only") and d["transport"] is None
+    g = d["gpu"]
+    assert g["compute_units"] == 256 and g["arch"].startswith("gfx950") and g["rocminfo"]["name"] == "gfx950"
+    r = d["roofline"]
+    assert 4000 < r["measured_write_ceiling_GBps"] < 8000
+    assert r["frac_of_measured_write_ceiling"] == pytest.approx(r["achieved"] / r["measured_write_ceiling_GBps"])
+    assert r["achieved"] <= 1.02 * r["measured_write_ceiling_GBps"]  # the kernel cannot beat a store-only kernel by much
+    one = d["api_path_one_launch"]
+    assert d["api_path_graphed_one_launch_env_steps_per_s"] == pytest.approx(65536 / (one["us_per_ply"] * 1e-6), rel=1e-6)
+    assert one["launch_floor_us"] < one["us_per_ply"] and one["alg_bytes_per_env_step"] == 142
+    assert d["api_path_graphed_one_launch_env_steps_per_s"] > d["api_path_graphed_fused_reset_env_steps_per_s"] > \
+        d["api_path_graphed_env_steps_per_s"]
+    w = d["with_action_log"]
+    assert w["log_bytes_per_env_step"] == 0.875 and "7-bit" in w["kernel_variant"] and 0.85 * d["value"] < w["value"] <= 1.02 * d["value"]
+    sp = d["selfplay"]
+    assert sp["eager_sink_add_copied_bytes_per_agent_step"] < 30 and sp["eager_copying_add_copied_bytes_per_agent_step"] == 750.0
+    assert sp["graphed_agent_steps_per_s"] > sp["eager_sink_agent_steps_per_s"]
+    assert sp["alg_bytes_per_agent_step"] <= 1.1 * sp["survey_B_agent_bytes"]
+
+
+def test_round3_rehearsal_lines_cover_every_exchange_mode():
+    with open(os.path.join(ROOT, "profiles", "r03_bench_gloo2_rehearsal_lines.json")) as f:
+        lines = [json.loads(x) for x in f.read().strip().splitlines()]
+    assert len(lines) == 4
+    per_step = [x["exchange"]["bytes_per_env_step"] for x in lines]
+    # keyframe every 8th chunk, every chunk, never (state once up front), packed records
+    assert per_step[0] == pytest.approx(0.875 + (36 + 4) / (256 * 8), abs=2e-3)   # 36 B state (+ padding) per keyframe
+    assert per_step[1] == pytest.approx(0.875 + (36 + 4) / 256, abs=2e-2)
+    assert per_step[2] == 0.875 and lines[2]["exchange"]["start_state_bytes_per_rank"] == 16384 * 36
+    assert per_step[3] == 28.0
+    for x in lines:
+        assert x["n_gpus"] == 2 and x["gather"] == x["config"]["gather"] and x["transport"] == x["exchange"]["transport"]
+        assert ("7-bit" in x["kernel_variant"]) == (x["gather"] == "actions")
