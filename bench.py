@@ -463,11 +463,18 @@ def replay_rate(env, roll, chunk, reps=8):
 
 
 def selfplay_mode(args):
+    print(json.dumps(selfplay_config3(args, min(args.steps * 4, 256), 64)), flush=True)
+
+
+def selfplay_config3(args, steps, warm):
     """BASELINE.json config 3: full self-play rollout through TorchSelfPlayWrapper with a small conv
     policy (the shape of the reference's cnn_b_s: 4 x [conv3x3(56) + BN + ReLU], 1x1-conv heads,
     alg/architectures/configs.py:49-56) as agent and a pool of 4 frozen opponents rotated every 64 steps.
     The networks are the caller's side of the boundary (PyTorch-ROCm / MIOpen, bf16 autocast, eval mode);
-    what this build contributes are the two env kernels and the fused mask+softmax+draw per step."""
+    what this build contributes are the two env kernels and the fused mask+softmax+draw per step.  Every agent-step is
+    stored: the wrapper is attached to a RolloutBuffer of 64 rows (the fused sink) and observations leave the kernels as
+    bf16 -- the dtype the networks' first convolution computes in under autocast -- so nothing is copied or cast on the
+    way from the step kernel to the buffer and to the network."""
     import torch.nn as nn
 
     import mnk_hip
@@ -526,23 +533,32 @@ def selfplay_mode(args):
     pool = OpponentPool(max_size=4)
     for net in nets[1:]:
         pool.add_opponent(FusedNNPolicy(net, seed=args.seed + 1))
-    env = TorchVectorMnkEnv(m, n, k, nenv, device=str(dev))
+    from alg.rollout_buffer import RolloutBuffer
+
+    env = TorchVectorMnkEnv(m, n, k, nenv, device=str(dev), obs_dtype=torch.bfloat16)
     wrap = TorchSelfPlayWrapper(env, seed=args.seed)
     opponents = list(pool.pool)
     wrap.set_opponent(opponents[0])
+    buf = RolloutBuffer(64, nenv, (2, m, n), c, device=str(dev), obs_dtype=torch.bfloat16)
+    wrap.attach_sink(buf)
     obs, _ = wrap.reset()
     state = {"obs": obs, "plies": torch.zeros((), dtype=torch.long, device=dev)}
+    zeros = torch.zeros(nenv, device=dev)
 
     def step(t):
         if t % 64 == 0:
             wrap.set_opponent(opponents[(t // 64) % len(opponents)])
+        if buf.ptr == buf.n_steps:
+            buf.ptr = 0  # the next rollout overwrites the rows (values / advantages are not part of this measurement)
         before = env._meta >> 1
-        actions = agent.act(state["obs"])
+        prev = state["obs"]
+        actions = agent.act(prev)
         state["obs"], rew, term, trunc, _ = wrap.step(actions)
+        buf.add(prev["observation"], actions, rew, zeros, zeros, term | trunc, prev["action_mask"])
         # plies played this step = growth of the move counters (resets restart them at 0 or 1)
         state["plies"] += torch.clamp((env._meta >> 1) - before, min=0).sum()
 
-    steps, warm = min(args.steps * 4, 256), 64  # agent-steps here, not kernel launches
+    # (steps / warm: agent-steps here, not kernel launches)
     for t in range(warm):
         step(t)
     state["plies"].zero_()
@@ -557,6 +573,7 @@ def selfplay_mode(args):
         def act(self, o):
             return torch.zeros(nenv, dtype=torch.long, device=dev)
     wrap.set_opponent(Const())
+    wrap.attach_sink(None)
     acts = torch.zeros(nenv, dtype=torch.long, device=dev)
     for _ in range(5):
         wrap.step(acts)
@@ -572,7 +589,9 @@ def selfplay_mode(args):
         "ms_per_step": dt * 1e3 / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64 env state; bf16 autocast policy (caller side)", "data": "synthetic",
         "config": {"workload": f"{m}x{n}x{k}, {nenv} envs, TorchSelfPlayWrapper loop, agent = opponent pool of 4 = "
-                               "random-init 4x conv3x3(56) policies, fused mask+softmax+draw", "envs_per_gpu": nenv},
+                               "random-init 4x conv3x3(56) policies, fused mask+softmax+draw, bf16 observations written "
+                               "straight into a RolloutBuffer (fused sink)", "envs_per_gpu": nenv},
+        "buffer_add_copied_bytes_per_agent_step": buf.copied_bytes / ((steps + warm) * nenv),
         "env_steps_per_s": float(state["plies"].item()) / dt,
         "env_side_ms_per_step": env_ms,
         "nn_and_sampling_ms_per_step": dt * 1e3 / steps - env_ms,
@@ -583,7 +602,7 @@ def selfplay_mode(args):
         "cpu_baseline": {"note": "the CPU baseline is reported on the headline workload (default --mode rollout)",
                          "value": None, "unit": "agent-steps/s", "cores": None, "kind": None, "sample": None},
     }
-    print(json.dumps(out), flush=True)
+    return out
 
 
 def spawn_ranks(n):
@@ -945,6 +964,14 @@ def main():
             out["replay_env_steps_per_s"] = replay_rate(env, roll, chunk)
             out["with_action_log"] = with_action_log_rate(roll, chunk, args.steps)
             out["selfplay"] = selfplay_object(m, n, k, nenv, args.seed, dev)
+            # BASELINE config 3 proper (conv policy as agent, pool of 4 network opponents), a short run of what
+            # `--mode selfplay` measures at length: the caller-side networks are >99 % of it
+            torch.cuda.empty_cache()
+            c3 = selfplay_config3(args, 48, 16)
+            out["selfplay"]["config3"] = {key: c3[key] for key in ("metric", "value", "unit", "ms_per_step", "env_steps_per_s",
+                                                                   "env_side_ms_per_step", "nn_and_sampling_ms_per_step",
+                                                                   "buffer_add_copied_bytes_per_agent_step")}
+            out["selfplay"]["config3"]["workload"] = c3["config"]["workload"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(env, args.cpu_seconds, args.cpu_threads)
         else:
