@@ -7,7 +7,9 @@ import pytest
 import torch
 
 from oracle.env_torch import OracleVectorEnv
+from oracle.packing import pack_boards
 from oracle.policies import HighestLegalPolicy, LowestLegalPolicy, MaskHashPolicy
+from oracle.rollout import encode_action_log, random_rollout
 from oracle.selfplay_torch import OracleSelfPlay
 
 pytestmark = pytest.mark.gpu
@@ -29,8 +31,10 @@ def hip():
     class NS:
         pass
 
+    from selfplay import random_rollout as rr
+
     ns = NS()
-    ns.Env, ns.Wrapper = TorchVectorMnkEnv, TorchSelfPlayWrapper
+    ns.Env, ns.Wrapper, ns.rollout, ns.lib = TorchVectorMnkEnv, TorchSelfPlayWrapper, rr, mnk_hip
     return ns
 
 
@@ -146,7 +150,14 @@ def test_wrapper_fuzz(hip, seed):
     nenv = int(rng.choice([1, 5, 64, 67, 200]))
     c = m * n
     opp = [LowestLegalPolicy, HighestLegalPolicy, MaskHashPolicy][seed % 3]
-    wrap = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV), seed=seed)
+    # round 3: the env hands out f32, bf16 or u8 observations, and some steps write into caller-owned tensors
+    obs_dtype = [torch.float32, torch.bfloat16, torch.uint8][seed % 3]
+    wrap = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV, obs_dtype=obs_dtype), seed=seed)
+    mine = {"observation": torch.empty((nenv, 2, m, n), dtype=[torch.uint8, torch.float32, torch.bfloat16][seed % 3], device=DEV),
+            "action_mask": torch.empty((nenv, c), dtype=torch.bool, device=DEV),
+            "rewards": torch.empty(nenv, dtype=torch.float32, device=DEV),
+            "terminated": torch.empty(nenv, dtype=torch.bool, device=DEV),
+            "packed": torch.empty((2, wrap.env.words, nenv), dtype=torch.int64, device=DEV)}
     ora = _ForcedSides(OracleVectorEnv(m, n, k, nenv))
     wrap.set_opponent(opp())
     ora.set_opponent(opp())
@@ -163,12 +174,92 @@ def test_wrapper_fuzz(hip, seed):
         sides = torch.from_numpy(rng.integers(0, 2, nenv))
         wrap.force_sides(sides)
         ora.sides = sides
-        o1, r1, t1, tr1, _ = wrap.step(torch.from_numpy(acts).to(DEV))
+        out = None
+        if rng.random() < 0.4:  # a random subset of the outputs goes to caller-owned tensors
+            out = {key: t_ for key, t_ in mine.items() if rng.random() < 0.6}
+        o1, r1, t1, tr1, _ = wrap.step(torch.from_numpy(acts).to(DEV), out=out)
         o2, r2, t2, tr2, _ = ora.step(torch.from_numpy(acts))
+        want_dtype = out["observation"].dtype if out and "observation" in out else obs_dtype
+        assert o1["observation"].dtype == want_dtype, where
+        for key, got in (("observation", o1["observation"]), ("action_mask", o1["action_mask"]), ("rewards", r1), ("terminated", t1)):
+            assert (got is out[key]) if out and key in out else True, f"{where}: {key} is not the caller's tensor"
+        if out and "packed" in out:
+            assert np.array_equal(out["packed"].cpu().numpy().view(np.uint64), pack_boards(o2["observation"].numpy(), m, n)), where
+        o1 = {"observation": o1["observation"].float(), "action_mask": o1["action_mask"]}
         _same_obs(o1, o2, where)
         assert torch.equal(r1.cpu(), r2) and torch.equal(t1.cpu(), t2) and not bool(tr1.any()), where
         assert torch.equal(wrap.agent_side.cpu(), ora.agent_side) and torch.equal(wrap.pending_resets.cpu(), ora.pending_resets), where
         _same_state(wrap.env, ora.env, where)
         if t % 7 == 3:
-            _same_obs(wrap.get_agent_obs(), ora.get_agent_obs(), where + " get_agent_obs")
+            got = wrap.get_agent_obs()
+            assert got["observation"].dtype == obs_dtype
+            _same_obs({"observation": got["observation"].float(), "action_mask": got["action_mask"]}, ora.get_agent_obs(),
+                      where + " get_agent_obs")
     wrap.env.check_errors()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_rollout_and_log_fuzz(hip, seed):
+    """Random boards, batch sizes and chunkings of the fused rollout with a random action-log format (byte, 16-bit, 7-bit
+    stream where the board allows), message kind (with / without the chunk-start state) and kernel choice (generic or
+    run-time specialised): records, statistics and final state == the oracle's raw loop; the log == the oracle's packing
+    of the recorded actions; a replay of every chunk -- from the message's own state or from the receiver's running
+    state -- rebuilds the records; one-launch plies (mnk_step_random) continue the same game stream ply for ply."""
+    import os
+
+    rng = np.random.default_rng(11000 + seed)
+    m, n, k = _shape(rng)
+    if n < 2:
+        n = 2
+    k = min(k, m, n)
+    nenv = int(rng.choice([1, 3, 64, 65, 129, 300]))
+    c = m * n
+    fmts = [hip.rollout.ACT_U16] + ([hip.rollout.ACT_U8] if c <= 256 else []) + ([hip.rollout.ACT_BITS7] if c <= 128 else [])
+    saved = os.environ.get("MNK_JIT")
+    os.environ["MNK_JIT"] = str(seed % 2)  # both kernels for boards without a built-in variant
+    hip.lib.reload_config()
+    try:
+        env, ora = hip.Env(m, n, k, nenv, device=DEV), OracleVectorEnv(m, n, k, nenv)
+        roll = hip.rollout.RandomRollout(env, seed=400 + seed, env_id0=17 * seed)
+        state = hip.rollout.gather_start_state(env)
+        step0 = 0
+        chunks = [int(4 * rng.integers(1, 12)) for _ in range(3)] + [int(rng.integers(1, 40))]  # only the last one ragged
+        for j, t in enumerate(chunks):
+            where = f"seed {seed} {m}x{n}x{k} N={nenv} chunk {j} ({t} plies)"
+            fmt = int(rng.choice(fmts))
+            with_state = bool(rng.random() < 0.5)
+            rec = roll.alloc(t, log_actions=fmt, with_state=with_state)
+            roll.run(t, out=rec)
+            planes, meta, stats = random_rollout(ora, seed=400 + seed, step0=step0, steps=t, env_id0=17 * seed)
+            step0 += t
+            assert np.array_equal(rec.planes.cpu().numpy().view(np.uint64), planes), where
+            assert np.array_equal(rec.meta.cpu().numpy().view(np.uint32), meta), where
+            want_log = encode_action_log((meta & 0xFFFF).astype(np.int64), fmt)
+            assert np.array_equal(rec.act.cpu().numpy().view(want_log.dtype), want_log), where + f" log format {fmt}"
+            logs = hip.rollout.GatheredLogs.empty(1, env.words if with_state else 0, nenv, t, c, DEV, fmt=fmt, with_state=with_state)
+            logs.msg.copy_(rec.msg.unsqueeze(0))
+            again = hip.rollout.replay_shard(logs, 0, m, n, k, state=None if with_state else state)
+            if with_state:  # the receiver's running state moves on either way
+                hip.rollout.replay_shard(logs, 0, m, n, k, state=state, record=False)
+            assert torch.equal(again.planes, rec.planes) and torch.equal(again.meta, rec.meta), where + " replay"
+            assert torch.equal(state.planes[0], env._planes) and torch.equal(state.meta[0], env._meta), where + " replay state"
+            _same_state(env, ora, where)
+        # the same stream continued ply by ply through the one-launch step
+        rew = torch.empty(nenv, dtype=torch.float32, device=DEV)
+        done = torch.empty(nenv, dtype=torch.bool, device=DEV)
+        mask = torch.empty((nenv, c), dtype=torch.bool, device=DEV)
+        acts = torch.empty(nenv, dtype=torch.long, device=DEV)
+        t = int(rng.integers(2, 10))
+        planes, meta, _ = random_rollout(ora, seed=400 + seed, step0=step0, steps=t, env_id0=17 * seed)
+        for j in range(t):
+            env.step_random_into(rew, done, mask, actions=acts, seed=400 + seed, step=step0 + j, env_id0=17 * seed)
+            assert np.array_equal(acts.cpu().numpy(), (meta[j] & 0xFFFF).astype(np.int64)), f"seed {seed} one-launch ply {j}"
+            assert np.array_equal(done.cpu().numpy(), ((meta[j] >> 24) & 1).astype(bool))
+        _same_state(env, ora, f"seed {seed} after the one-launch plies")
+        assert torch.equal(mask.cpu(), ora.observe()["action_mask"])
+    finally:
+        if saved is None:
+            os.environ.pop("MNK_JIT", None)
+        else:
+            os.environ["MNK_JIT"] = saved
+        hip.lib.reload_config()
