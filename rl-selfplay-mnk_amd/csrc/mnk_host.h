@@ -70,8 +70,8 @@ struct MnkConfig {
   int form = 0;            // MNK_ROLLOUT_FORM=lane|pair|pairw|ws2|ws4 -> 1..5 (unset / unknown: 0)
   int jit = -1;            // MNK_JIT=0/1 (unset: run-time specialisation from 2^20 env-steps per launch)
   bool saddr_off = false;  // MNK_ROLLOUT_SADDR=0: no 32-bit-offset record stores
-  int emit_envs = 0;       // MNK_EMIT_ENVS=16|32|64: envs per workgroup of the write-out kernels (0: by batch size)
-  int emit_threads = 256;  // MNK_EMIT_THREADS=64|128|256 (the kernels are __launch_bounds__(256))
+  int emit_envs = 0;       // MNK_EMIT_ENVS=16|32|64|128: envs per workgroup of the write-out kernels (0: by batch size)
+  int emit_threads = 0;    // MNK_EMIT_THREADS=64|128|256 (the kernels are __launch_bounds__(256); 0: by output set)
 };
 enum { MNK_FORM_NONE = 0, MNK_FORM_LANE, MNK_FORM_PAIR, MNK_FORM_PAIRW, MNK_FORM_WS2, MNK_FORM_WS4 };
 
@@ -90,11 +90,11 @@ inline const MnkConfig& mnk_config(bool reload = false) {
     if (const char* v = getenv("MNK_ROLLOUT_SADDR")) c.saddr_off = atoi(v) == 0;
     if (const char* v = getenv("MNK_EMIT_ENVS")) {
       const int t = atoi(v);
-      c.emit_envs = (t == 16 || t == 32 || t == 64) ? t : 0;
+      c.emit_envs = (t == 16 || t == 32 || t == 64 || t == 128) ? t : 0;
     }
     if (const char* v = getenv("MNK_EMIT_THREADS")) {
       const int t = atoi(v);
-      c.emit_threads = (t == 64 || t == 128 || t == 256) ? t : 256;  // anything else would break the launch bounds
+      c.emit_threads = (t == 64 || t == 128 || t == 256) ? t : 0;  // anything else would break the launch bounds
     }
     cfg = c;
     loaded = true;
@@ -112,7 +112,13 @@ inline int mnk_block_envs(int64_t items) {
 
 // threads per workgroup of those kernels: the first 64 lanes play their envs, then all waves of
 // the workgroup sweep its output slab (more waves per SIMD to hide the LDS / store latency)
-inline int mnk_block_threads() { return mnk_config().emit_threads; }
+// 256 when an observation is written (1.3-1.7x faster than 64, tools/exp_emit.py); 128 when only the legal mask leaves
+// (an eighth of the bytes: two waves sweep it as fast as four and start sooner -- mnk_step_random at 65 536 envs 4.77 ->
+// 4.68 us per ply, at 262 144 envs 11.0 -> 9.5, tools/exp_one_launch.py)
+inline int mnk_block_threads(bool writes_obs = true) {
+  if (const int forced = mnk_config().emit_threads) return forced;
+  return writes_obs ? 256 : 128;
+}
 
 // Kernel variants: NW = u32 register words per plane; CN / CK = compile-time board width and
 // run length (0 = run time).  The boards people actually train on get fully specialised code

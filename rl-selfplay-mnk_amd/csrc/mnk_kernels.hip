@@ -621,7 +621,7 @@ int mnk_observe(const uint64_t* planes, const uint32_t* meta, int64_t N, int m, 
   const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
   const size_t lds = mnk_stage_bytes(g.NW, g.C, B, g.n, g.k);
   const dim3 grid((unsigned)((N + B - 1) / B));
-  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_observe), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, planes, N,
+  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_observe), grid, dim3(mnk_block_threads(obs != nullptr)), lds, (hipStream_t)stream, g, planes, N,
                                          flip_side, obs, obs_dtype, legal_mask, fix_empty_mask, packed_obs, vec_ok, B));
   return mnk_launch_status("observe");
 }
@@ -654,11 +654,11 @@ static int mnk_launch_step_full(const MnkGeom& g, uint64_t* planes, uint32_t* me
   const dim3 grid((unsigned)((N + B - 1) / B));
   const MnkDraw none = {0, 0, nullptr, 0, 0, nullptr};
   if (draw)
-    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_full<NW, CN, CK, true>), grid, dim3(mnk_block_threads()), lds, s,
+    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_full<NW, CN, CK, true>), grid, dim3(mnk_block_threads(obs != nullptr)), lds, s,
                                        g, planes, meta, N, actions, *draw, rewards, dones, legal_mask, obs, obs_dtype, err,
                                        flags, vec_ok, B));
   else
-    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_full<NW, CN, CK, false>), grid, dim3(mnk_block_threads()), lds, s,
+    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_full<NW, CN, CK, false>), grid, dim3(mnk_block_threads(obs != nullptr)), lds, s,
                                        g, planes, meta, N, actions, none, rewards, dones, legal_mask, obs, obs_dtype, err,
                                        flags, vec_ok, B));
   return mnk_launch_status(draw ? "step_random" : "step");

@@ -24,7 +24,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
           f"N={nenv}: {us:6.2f} us per ply  {rate:.3e} env-steps/s  (floor {floor:.2f} us)", flush=True)
 else:
     for nenv in (65536, 262144):
-        for envs in ("16", "32", "64"):
-            for threads in ("64", "128", "256"):
+        for envs in ("32", "64", "128"):
+            for threads in ("128", "256"):
                 e = dict(os.environ, MNK_EMIT_ENVS=envs, MNK_EMIT_THREADS=threads)
                 subprocess.run([sys.executable, os.path.abspath(__file__), "child", str(nenv)], env=e, check=False)
