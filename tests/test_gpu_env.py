@@ -340,6 +340,48 @@ def test_rollout_is_independent_of_sharding(hip):
     assert torch.equal(whole.meta, torch.cat([p.meta for p in parts], dim=1))
 
 
+@pytest.mark.parametrize("m,n,k,nenv,warm,plies", [
+    (9, 9, 5, 65536, 152, 12),      # BASELINE configs 2 / 4: one lane per env, the FAST loop
+    (19, 19, 5, 32768, 400, 4),     # BASELINE config 5's per-GPU batch: two lanes per env, board split by words
+    (13, 13, 5, 65536, 200, 4),
+])
+def test_full_size_rollout_equals_the_oracle_ply_for_ply(hip, m, n, k, nenv, warm, plies):
+    """Bit-exact parity AT the BASELINE.json batch sizes, not only properties: the device plays `warm` plies (a
+    stationary mix of game phases, finished games restarting), the whole state goes to the CPU oracle, and then both
+    play the same `plies` plies -- the oracle's raw loop (RandomPolicy with the Philox draw -> env.step ->
+    env.reset(done)) against ONE launch of the fused kernel, and against the same plies through mnk_step_random:
+    records, statistics and the final state of all 65 536 / 32 768 envs equal."""
+    env = hip.Env(m, n, k, nenv, device=DEV)
+    roll = hip.Rollout(env, seed=3, env_id0=1 << 20)
+    roll.run(warm, record=False)
+    ora = OracleVectorEnv(m, n, k, nenv)
+    ora.boards.copy_(env.boards.cpu())
+    ora.current_player.copy_(env.current_player.cpu())
+    ora.move_counts.copy_(env.move_counts.cpu())
+    twin = hip.Env(m, n, k, nenv, device=DEV)
+    twin.load_state_dict(env.state_dict())
+    before = roll.stats.cpu().numpy().copy()
+    rec = roll.run(plies)
+    planes, meta, stats = random_rollout(ora, seed=3, step0=warm, steps=plies, env_id0=1 << 20)
+    assert int(stats[0]) > 0, "no game finished in the compared plies: lengthen them"
+    assert np.array_equal(rec.planes.cpu().numpy().view(np.uint64), planes)
+    assert np.array_equal(rec.meta.cpu().numpy().view(np.uint32), meta)
+    assert np.array_equal(roll.stats.cpu().numpy() - before, stats)
+    assert np.array_equal(pack_boards(env.boards.cpu().numpy(), m, n), pack_boards(ora.boards.numpy(), m, n))
+    assert torch.equal(env.current_player.cpu(), ora.current_player) and torch.equal(env.move_counts.cpu(), ora.move_counts)
+    # the same plies, one launch each
+    rew = torch.empty(nenv, dtype=torch.float32, device=DEV)
+    done = torch.empty(nenv, dtype=torch.bool, device=DEV)
+    acts = torch.empty(nenv, dtype=torch.long, device=DEV)
+    mask = torch.empty((nenv, m * n), dtype=torch.bool, device=DEV)
+    for j in range(plies):
+        twin.step_random_into(rew, done, mask, actions=acts, seed=3, step=warm + j, env_id0=1 << 20)
+        assert np.array_equal(acts.cpu().numpy(), (meta[j] & 0xFFFF).astype(np.int64)), j
+        assert np.array_equal(done.cpu().numpy(), ((meta[j] >> 24) & 1).astype(bool)), j
+    assert torch.equal(twin._planes, env._planes) and torch.equal(twin._meta, env._meta)
+    assert torch.equal(mask.cpu(), ora.observe()["action_mask"])
+
+
 @pytest.mark.parametrize("m,n,k,nenv,steps,tail", [
     (9, 9, 5, 65536, 160, 640),       # BASELINE configs 2 / 4: one lane per env
     (19, 19, 5, 32768, 120, 2400),    # BASELINE config 5's per-GPU batch: two lanes per env

@@ -8,7 +8,7 @@ from oracle import philox
 from oracle.env_torch import OracleVectorEnv
 from oracle.packing import pack_boards, pack_cells, planes_from_record_rows, unpack_boards
 from oracle.policies import (FixedCellPolicy, HighestLegalPolicy, LowestLegalPolicy, MaskHashPolicy,
-                             PhiloxOpponent)
+                             PhiloxOpponent, RowSaltedHashPolicy)
 from oracle.rollout import gae as oracle_gae
 from oracle.selfplay_torch import OracleSelfPlay
 from conftest import random_play_stats
@@ -181,6 +181,57 @@ def test_fused_random_opponent_step_matches_oracle(hip, m, n, k, nenv, steps):
         assert torch.equal(r1.cpu(), r2) and torch.equal(t1.cpu(), t2), f"rewards / terminated {t}"
         assert torch.equal(wrap.pending_resets.cpu(), ora.pending_resets)
         same(o1, o2, t)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_full_size_selfplay_step_equals_the_oracle(hip, fused):
+    """Bit-exact parity of the wrapper AT the BASELINE.json size (9x9x5, 65 536 envs): reset + 28 agent-steps against
+    OracleSelfPlay -- the one-launch step with the built-in Philox opponent, and the two-launch step (k_selfplay_pre ->
+    policy -> k_selfplay_post) with a row-local deterministic opponent: observation, mask, rewards, terminated, sides,
+    pending resets and the env state of every env after every step.  The agent's move depends on the row (every env
+    plays its own game); games end from the fifth step on, so the later steps cover terminations and the resets after
+    them."""
+    m, n, k, nenv, seed, steps = 9, 9, 5, 65536, 41, 28
+    env = hip.Env(m, n, k, nenv, device=DEV)
+    wrap = hip.Wrapper(env, seed=seed)
+    ids = np.arange(nenv, dtype=np.uint64)
+    state = {"step": 0, "resetting": None}
+
+    def sides(count):
+        s_ = torch.from_numpy(philox.draw_side(philox.rand_u32(seed, ids, state["step"], philox.STREAM_SIDE)))
+        return s_ if count == nenv else s_[torch.nonzero(state["resetting"]).squeeze(1)]
+
+    ora = OracleSelfPlay(OracleVectorEnv(m, n, k, nenv), side_source=sides)
+    if fused:
+        wrap.set_opponent(hip.policy.RandomPolicy(m * n))
+        opp = PhiloxOpponent(seed, 0)
+        ora.set_opponent(opp)
+    else:
+        opp = None
+        wrap.set_opponent(MaskHashPolicy(5))
+        ora.set_opponent(MaskHashPolicy(5))
+    o1, _ = wrap.reset()
+    o2, _ = ora.reset()
+    agent = RowSaltedHashPolicy(11)  # deterministic, different in every row: the same agent moves on both sides
+    finished = 0
+    for t in range(steps + 1):
+        assert torch.equal(o1["observation"].cpu(), o2["observation"]) and torch.equal(o1["action_mask"].cpu(), o2["action_mask"]), t
+        assert torch.equal(wrap.agent_side.cpu(), ora.agent_side) and torch.equal(wrap.pending_resets.cpu(), ora.pending_resets), t
+        assert torch.equal(env._meta.cpu() & 1, ora.env.current_player.to(torch.int32)), t
+        if t == steps:
+            break
+        state["step"] = t + 1
+        if opp is not None:
+            opp.step = t + 1
+        state["resetting"] = ora.pending_resets.clone()
+        acts = agent.act(o2)
+        o1, r1, t1, _, _ = wrap.step(acts.to(DEV))
+        o2, r2, t2, _, _ = ora.step(acts)
+        assert torch.equal(r1.cpu(), r2) and torch.equal(t1.cpu(), t2), t
+        finished += int(t2.sum())
+    assert np.array_equal(pack_boards(env.boards.cpu().numpy(), m, n), pack_boards(ora.env.boards.numpy(), m, n))
+    assert torch.equal(env.move_counts.cpu(), ora.env.move_counts)
+    assert finished > 100, f"only {finished} games ended in the compared steps: terminations and resets went untested"
 
 
 def test_two_launch_path_equals_fused_path(hip):
