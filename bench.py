@@ -434,7 +434,7 @@ def with_action_log_rate(roll, chunk, steps):
     n = roll.env.num_envs
     return {"value": n * chunk / (ms * 1e-3), "unit": "env-steps/s", "avg_launch_us": ms * 1e3,
             "kernel_variant": "records + action log " + {1: "(one byte per action)", 2: "(two bytes per action)",
-                                                         3: "(7-bit stream)"}[rec.fmt],
+                                                         3: "(7-bit stream)", 4: "(a byte and a bit per action)"}[rec.fmt],
             "log_bytes_per_env_step": rec.msg.numel() * 8 / (n * chunk)}
 
 
@@ -876,8 +876,8 @@ def main():
         # what exactly ran (the driver compares its N = 1 point with the one-GPU line): the exchange mode, the kernel
         # variant that mode implies, and the transport of the collective
         "gather": mode,
-        "kernel_variant": "records + action log " + {1: "(one byte per action)", 2: "(two bytes per action)",
-                                                     3: "(7-bit stream)"}[bufs[0].fmt] if logging
+        "kernel_variant": "records + action log " + {1: "(one byte per action)", 2: "(two bytes per action)", 3: "(7-bit stream)",
+                                                     4: "(a byte and a bit per action)"}[bufs[0].fmt] if logging
                           else "records only (no action log)",
         "transport": None,
         "roofline": {
@@ -914,7 +914,7 @@ def main():
         compute_ms = world * nenv * plies / compute_only * 1e3 / args.steps
         exposed_ms = max(0.0, step_ms - compute_ms)
         out["exchange"] = {
-            "what": {"actions": "the action log (7-bit stream up to 128 cells, else 1-2 bytes per action)" +
+            "what": {"actions": "the action log (7-bit stream up to 128 cells, a byte up to 256, a byte and a bit beyond)" +
                                 (f"; every {keyframe}th chunk's message also carries the chunk-start state (keyframe), "
                                  "records of any chunk are rebuilt on demand from the last keyframe + the logs since"
                                  if keyframe > 1 else "; every message carries the chunk-start state (self-contained)"

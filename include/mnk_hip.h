@@ -89,6 +89,11 @@ extern "C" {
                          * [mnk_action_log_words(MNK_ACT_BITS7, T)][N] -- 0.875 B per env-step, what the ranks of
                          * BASELINE.json configs 2-4 (9x9: 81 cells) put on xGMI */
 
+#define MNK_ACT_U8P1 4  /* 9 bits per action, boards of more than 256 cells (19x19: 361): the low bytes as in MNK_ACT_U8,
+                         * u32[ceil(T/4)][N], followed by a bit plane of bit 8 of every action, ply p at bit p % 32 of
+                         * word [ceil(T/4) + p / 32][i], u32[ceil(T/32)][N] -- 1.125 B per env-step where MNK_ACT_U16 takes 2
+                         * (BASELINE.json config 5's exchange) */
+
 /* bytes of the opaque communicator id exchanged between ranks (= NCCL_UNIQUE_ID_BYTES) */
 #define MNK_COMM_ID_BYTES 128
 
@@ -273,7 +278,7 @@ const char* mnk_jit_last_error(void);
  * rebuilds rec_planes / rec_meta bit-identical to what the sender recorded (both may be NULL to only
  * advance the state).  An action >= m*n in the log is reported through err. */
 /* 32-bit words per env of a T-ply log in format `act_bytes` (0 for an unknown format): U8 ceil(T/4), U16 2 ceil(T/4),
- * BITS7 ceil(7 ceil(T/4) / 8) */
+ * BITS7 ceil(7 ceil(T/4) / 8), U8P1 ceil(T/4) + ceil(T/32) */
 int mnk_action_log_words(int act_bytes, int T);
 int mnk_replay_actions(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, int T,
                        const void* act_log, int act_bytes, uint64_t* rec_planes, uint32_t* rec_meta,

@@ -108,7 +108,7 @@ def gae(rewards, values, dones, last_values, gamma=0.99, lam=0.95):
 
 
 # ---- action-log formats of the multi-GPU exchange (include/mnk_hip.h MNK_ACT_*), restated in numpy
-ACT_U8, ACT_U16, ACT_BITS7 = 1, 2, 3
+ACT_U8, ACT_U16, ACT_BITS7, ACT_U8P1 = 1, 2, 3, 4
 
 
 def encode_action_log(actions, fmt: int) -> np.ndarray:
@@ -116,10 +116,18 @@ def encode_action_log(actions, fmt: int) -> np.ndarray:
     ACT_U8    uint32 [ceil(T/4), N]   action of ply 4q+j in byte j of word q
     ACT_U16   uint64 [ceil(T/4), N]   ... in 16-bit field j
     ACT_BITS7 uint32 [ceil(7 ceil(T/4) / 8), N]   a bit stream per env, action of ply p at bits [7p, 7p+7)
+    ACT_U8P1  uint32 [ceil(T/4) + ceil(T/32), N]  the ACT_U8 words of the low bytes, then bit 8 of ply p at bit p % 32
+                                                  of word ceil(T/4) + p // 32
     Plies past T count as action 0."""
     a = np.asarray(actions, dtype=np.uint64)
     t, n = a.shape
     q = (t + 3) // 4
+    if fmt == ACT_U8P1:
+        assert (a < 512).all()
+        high = np.zeros(((t + 31) // 32, n), dtype=np.uint32)
+        for p in range(t):
+            high[p // 32] |= ((a[p] >> np.uint64(8)) & np.uint64(1)).astype(np.uint32) << np.uint32(p % 32)
+        return np.concatenate([encode_action_log(a & np.uint64(0xFF), ACT_U8), high])
     a = np.concatenate([a, np.zeros((4 * q - t, n), dtype=np.uint64)])
     if fmt in (ACT_U8, ACT_U16):
         bits = 8 if fmt == ACT_U8 else 16
@@ -141,6 +149,11 @@ def encode_action_log(actions, fmt: int) -> np.ndarray:
 def decode_action_log(log, steps: int, fmt: int) -> np.ndarray:
     """inverse of ``encode_action_log``: int64 actions [steps, N]"""
     log = np.asarray(log)
+    if fmt == ACT_U8P1:
+        q = (steps + 3) // 4
+        low = decode_action_log(log[:q], steps, ACT_U8)
+        high = np.stack([(log[q + p // 32].astype(np.int64) >> (p % 32)) & 1 for p in range(steps)]) if steps else low
+        return low | (high << 8)
     if fmt in (ACT_U8, ACT_U16):
         bits = 8 if fmt == ACT_U8 else 16
         w = log.astype(np.uint64)

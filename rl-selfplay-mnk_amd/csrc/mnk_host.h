@@ -141,6 +141,12 @@ inline int mnk_block_threads(bool writes_obs = true) {
     else MNK_CASE(16, 0, 0, __VA_ARGS__)                                              \
   } while (0)
 #define MNK_K(name) HIP_KERNEL_NAME(name<NW, CN, CK>)
+// the variants a board of more than 256 cells can have (MNK_ACT_U8P1): 19x19x5 and the generic 16-word form
+#define MNK_DISPATCH_LARGE(g, ...)                                                       \
+  do {                                                                                   \
+    if ((g).n == 19 && (g).k == 5 && (g).NW == 12) MNK_CASE(12, 19, 5, __VA_ARGS__)      \
+    else MNK_CASE(16, 0, 0, __VA_ARGS__)                                                 \
+  } while (0)
 // the variants a board of at most 128 cells can have (the 7-bit action stream): 9x9x5, 3x3x3, generic up to 8 words
 #define MNK_DISPATCH_SMALL(g, ...)                                                    \
   do {                                                                                \
@@ -161,7 +167,8 @@ inline bool mnk_rollout_saddr_ok(const MnkGeom& g, int64_t N, int T) {
 
 // is `act` a log format this board can use?  (0 = no log)
 inline bool mnk_act_format_ok(int act, int C) {
-  return act == 0 || act == MNK_ACT_U16 || (act == MNK_ACT_U8 && C <= 256) || (act == MNK_ACT_BITS7 && C <= 128);
+  return act == 0 || act == MNK_ACT_U16 || (act == MNK_ACT_U8 && C <= 256) || (act == MNK_ACT_BITS7 && C <= 128) ||
+         (act == MNK_ACT_U8P1 && C > 256);  // (U8P1 would hold any board; only the boards that need it have kernel variants)
 }
 
 // one-lane rollout variants that write the action log (mnk_rollout_log.hip); act_bytes is 1 or 2

@@ -69,6 +69,37 @@ k_replay_actions(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, 
     L.store(planes, meta, i);
     return;
   }
+  if constexpr (ACTB == 4) {  // MNK_ACT_U8P1: a word of four low bytes per group, a word of 32 high bits per 32 plies
+    bool bad9 = false;
+    auto play9 = [&](uint32_t a) {
+      if (a >= (uint32_t)g.C) { bad9 = true; a = 0; }
+      L.ply_action((int)a);
+    };
+    const int quads = (T + 3) >> 2, hwords = (T + 31) >> 5;
+    const uint32_t* lo = (const uint32_t*)act_log + i;
+    const uint32_t* hi = lo + (int64_t)quads * N;
+    uint32_t ahead = quads ? lo[0] : 0u;
+    uint32_t hbits = hwords ? hi[0] : 0u;
+    int t = 0;
+    for (int q = 0; t < T; ++q) {
+      const uint32_t word = ahead;
+      ahead = lo[(int64_t)(q + 1 < quads ? q + 1 : q) * N];
+      if (q && (q & 7) == 0) hbits = hi[(int64_t)(q >> 3) * N];  // plies 4q .. 4q+3 are bits (4q .. 4q+3) % 32 of word q / 8
+      const uint32_t h4 = hbits >> (4 * (q & 7));
+      if (t + 4 <= T) {
+        play9((word & 0xFFu) | ((h4 & 1u) << 8));
+        play9(((word >> 8) & 0xFFu) | ((h4 & 2u) << 7));
+        play9(((word >> 16) & 0xFFu) | ((h4 & 4u) << 6));
+        play9((word >> 24) | ((h4 & 8u) << 5));
+        t += 4;
+      } else {
+        for (int j = 0; t < T; ++t, ++j) play9(((word >> (8 * j)) & 0xFFu) | (((h4 >> j) & 1u) << 8));
+      }
+    }
+    if (bad9) mnk_report(err, MNK_ERR_ACTION_RANGE, i);
+    L.store(planes, meta, i);
+    return;
+  }
   constexpr uint32_t FIELD = ACTB == 1 ? 0xFFu : 0xFFFFu;
   auto fetch = [&](int q) -> uint64_t {
     if (ACTB == 1) return (uint64_t)((const uint32_t*)act_log)[(int64_t)q * N + i];
@@ -146,14 +177,15 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   // by directions / by words: 19x19 216 / 164, 15x15 155 / 135, 13x13 127 / 117; 9x9 86 / 98 stays split by
   // directions); MNK_ROLLOUT_FORM=pair|pairw forces one (pairw at any batch size)
   const bool force_w = cfg.form == MNK_FORM_PAIRW;
-  const bool force_d = cfg.form == MNK_FORM_PAIR;
+  // (the direction-split pair form writes byte / 16-bit logs only: a launch with a bit-packed log takes the word split)
+  const bool force_d = cfg.form == MNK_FORM_PAIR && act_bytes != MNK_ACT_U8P1;
   if (mnk_rollout_pairw_supported(g) && w_fits && act_bytes != MNK_ACT_BITS7 &&
       (force_w || (use_pair && !force_d && g.n >= 13))) {
     mnk_launch_rollout_pairw(g, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,
                              rec ? rec_meta : nullptr, stats, act_log, act_bytes, stream);
     return mnk_launch_status("rollout_random_pairw");
   }
-  if (use_pair) {
+  if (use_pair && act_bytes != MNK_ACT_U8P1) {
     mnk_launch_rollout_pair(g, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,
                             rec ? rec_meta : nullptr, stats, act_log, act_bytes, stream);
     return mnk_launch_status("rollout_random_pair");
@@ -196,6 +228,7 @@ int mnk_action_log_words(int act_bytes, int T) {
   if (act_bytes == MNK_ACT_U8) return q;
   if (act_bytes == MNK_ACT_U16) return 2 * q;
   if (act_bytes == MNK_ACT_BITS7) return (7 * q + 7) >> 3;
+  if (act_bytes == MNK_ACT_U8P1) return q + ((T + 31) >> 5);
   return 0;
 }
 
@@ -214,7 +247,15 @@ int mnk_replay_actions(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
                                      (hipStream_t)stream, g, planes, meta, N, T, act_log, REC ? rec_planes : nullptr, \
                                      REC ? rec_meta : nullptr, err))
   const bool rec = rec_planes && rec_meta;
-  if (act_bytes == MNK_ACT_BITS7) {
+  if (act_bytes == MNK_ACT_U8P1) {
+#define MNK_REPLAY9(REC)                                                                                               \
+  MNK_DISPATCH_LARGE(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_replay_actions<NW, CN, CK, REC, 4>), grid, dim3(B), 0,    \
+                                           (hipStream_t)stream, g, planes, meta, N, T, act_log,                        \
+                                           REC ? rec_planes : nullptr, REC ? rec_meta : nullptr, err))
+    if (rec) MNK_REPLAY9(true);
+    else MNK_REPLAY9(false);
+#undef MNK_REPLAY9
+  } else if (act_bytes == MNK_ACT_BITS7) {
 #define MNK_REPLAY7(REC)                                                                                               \
   MNK_DISPATCH_SMALL(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_replay_actions<NW, CN, CK, REC, 3>), grid, dim3(B), 0,    \
                                            (hipStream_t)stream, g, planes, meta, N, T, act_log,                        \

@@ -26,6 +26,9 @@
 // are scalar: seven word stores per 32 plies, three 32-bit VALU operations per quad besides the store.  (A 64-bit
 // accumulator -- the obvious spelling -- made every field shift a v_lshlrev_b64: 106.6 instead of 95 us per 256 plies.)
 // One-lane form only.
+// ACT = 4 (MNK_ACT_U8P1, boards of more than 256 cells): the low byte of every action exactly as ACT = 1, plus bit 8 of
+// every action in a bit plane behind the byte words: four plies' bits gather at compile-time positions, the groups go
+// into one word per 32 plies at a wave-uniform position -- one more VALU operation per ply and one more store per 32.
 // PAIR: the two-lanes-per-env form for small batches (mnk_rollout_pair.hip): both lanes of a pair carry the env and
 // pick the move redundantly; lane `role` scans two of the four directions (one DPP swap ORs the verdicts), writes
 // half `role` of every record row and stores plane `role` of the final state.
@@ -66,7 +69,9 @@ struct RolloutLane {
   uint32_t roff = 0, moff = 0;  // ... and this lane's byte offsets of rec_planes[t][0][i] / rec_meta[t][i]
   uint8_t* ra = nullptr;   // act_log[t / 4][i]  (ACT 3: the next word of the 7-bit stream, [w][i])
   uint64_t quad = 0;       // the actions of the current group of four plies
-  uint32_t q32 = 0;        // ACT 3: the same, 4 x 7 bits
+  uint32_t q32 = 0;        // ACT 3: the same, 4 x 7 bits; ACT 4: the low bytes of the group
+  uint8_t* rh = nullptr;   // ACT 4: the next word of the bit plane of bit 8, [ceil(T/4) + p/32][i]
+  uint32_t hi4 = 0, hiw = 0, hfill = 0;  // ACT 4: bit 8 of the group's actions, the word being filled, its fill (uniform)
   uint32_t lo = 0;         // ACT 3: the stream's accumulator: the bits of the word being filled ...
   uint32_t fill = 0;       // ... and how many of them are valid (wave-uniform: 0, 28, 24, ..., 4 between quads)
   // per-lane statistics, one add each per ply (T <= 65535 per launch): draws = done - wins, black wins =
@@ -91,8 +96,13 @@ struct RolloutLane {
         moff = (uint32_t)i * 4u;
       }
     }
-    static_assert(ACT != 3 || (!PAIR && WS == 1), "the 7-bit action stream is built into the one-lane form only");
-    if (ACT) ra = (uint8_t*)act_log + i * 4 * (ACT == 3 ? 1 : ACT);
+    static_assert((ACT != 3 && ACT != 4) || (!PAIR && WS == 1), "the bit-packed action logs are built into the one-lane form only");
+    if (ACT) ra = (uint8_t*)act_log + i * 4 * (ACT == 2 ? 2 : 1);
+  }
+
+  // ACT 4: where the bit plane starts depends on the launch's length
+  __device__ __forceinline__ void log_begin(void* act_log, int T, int64_t i) {
+    if constexpr (ACT == 4) rh = (uint8_t*)act_log + ((int64_t)((T + 3) >> 2) * N + i) * 4;
   }
 
   __device__ __forceinline__ void load(const uint64_t* planes, const uint32_t* meta, int64_t i) {
@@ -185,6 +195,21 @@ struct RolloutLane {
       q32 = 0;
       return;
     }
+    if constexpr (ACT == 4) {  // the four low bytes as one word; the four high bits into the plane's current word
+      *(uint32_t*)ra = q32;
+      ra += N * 4;
+      q32 = 0;
+      hiw |= hi4 << hfill;
+      hi4 = 0;
+      hfill += 4u;
+      if (hfill == 32u) {
+        *(uint32_t*)rh = hiw;
+        rh += N * 4;
+        hiw = 0;
+        hfill = 0;
+      }
+      return;
+    }
     if (WS == 1 || wrole == 0) {
       if (ACT == 1) *(uint32_t*)ra = (uint32_t)quad;
       if (ACT == 2) *(uint64_t*)ra = quad;
@@ -198,6 +223,9 @@ struct RolloutLane {
     if (ACT && (T & 3)) log_flush();
     if constexpr (ACT == 3) {
       if (fill) *(uint32_t*)ra = lo;
+    }
+    if constexpr (ACT == 4) {
+      if (hfill) *(uint32_t*)rh = hiw;
     }
   }
 
@@ -233,6 +261,10 @@ struct RolloutLane {
     const int a = pick<FAST>(x, hot, nlegal);
     if constexpr (ACT == 3) {
       q32 |= (uint32_t)a << (7 * field);
+      if (field == 3) log_flush();
+    } else if constexpr (ACT == 4) {
+      q32 |= ((uint32_t)a & 0xFFu) << (8 * field);
+      hi4 |= ((uint32_t)a >> 8) << field;
       if (field == 3) log_flush();
     } else if (ACT) {
       quad |= (uint64_t)(uint32_t)a << (8 * ACT * field);
@@ -376,6 +408,7 @@ __device__ __forceinline__ void rollout_random_body(const MnkGeom& g, uint64_t* 
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) {
     RolloutLane<NW, CN, CK, RECORD, ACT, false, 1, SADDR> L(g, N, i, rec_planes, rec_meta, act_log);
+    L.log_begin(act_log, T, i);
     L.load(planes, meta, i);
     const uint64_t env = (uint64_t)(env_id0 + i);
     // every lane of this wave in a consistent game (any state the env produced itself): the FAST loop; a wave that

@@ -18,7 +18,8 @@ void mnk_launch_rollout_log(const MnkGeom& g, uint64_t* planes, uint32_t* meta, 
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NWv, CNv, CKv, true, ACTB, true>), grid, dim3(B), 0,            \
                      (hipStream_t)stream, g, planes, meta, N, T, seed, step0, env_id0, rec_planes, rec_meta,          \
                      (unsigned long long*)stats, act_log)
-    if (g.n == 19) MNK_SADDR(12, 19, 5, 2);                      // 361 cells: two bytes per action
+    if (g.n == 19 && act_bytes == MNK_ACT_U8P1) MNK_SADDR(12, 19, 5, 4);  // 361 cells: a byte and a bit per action ...
+    else if (g.n == 19) MNK_SADDR(12, 19, 5, 2);                 // ... or two bytes
     else if (act_bytes == MNK_ACT_BITS7) {                        // 7-bit stream: boards of at most 128 cells
       if (g.n == 9) MNK_SADDR(3, 9, 5, 3);
       else MNK_SADDR(1, 3, 3, 3);
@@ -40,7 +41,15 @@ void mnk_launch_rollout_log(const MnkGeom& g, uint64_t* planes, uint32_t* meta, 
   MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NW, CN, CK, REC, ACTB>), grid, dim3(B), 0, \
                                      (hipStream_t)stream, g, planes, meta, N, T, seed, step0, env_id0,           \
                                      rec_planes, rec_meta, (unsigned long long*)stats, act_log))
-  if (act_bytes == MNK_ACT_BITS7) {
+  if (act_bytes == MNK_ACT_U8P1) {  // boards of more than 256 cells: 19x19 and the generic 16-word form
+#define MNK_ROLLOUT9(REC)                                                                                          \
+  MNK_DISPATCH_LARGE(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NW, CN, CK, REC, 4>), grid, dim3(B), 0, \
+                                           (hipStream_t)stream, g, planes, meta, N, T, seed, step0, env_id0,       \
+                                           rec_planes, rec_meta, (unsigned long long*)stats, act_log))
+    if (rec) MNK_ROLLOUT9(true);
+    else MNK_ROLLOUT9(false);
+#undef MNK_ROLLOUT9
+  } else if (act_bytes == MNK_ACT_BITS7) {
     // boards of at most 128 cells: 9x9, 3x3 and generic boards of up to 8 register words (e.g. 11x11 = 121 cells, NW 5)
 #define MNK_ROLLOUT7(REC)                                                                                          \
   MNK_DISPATCH_SMALL(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NW, CN, CK, REC, 3>), grid, dim3(B), 0, \

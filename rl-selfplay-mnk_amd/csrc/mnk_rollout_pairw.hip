@@ -38,6 +38,8 @@ struct RolloutPairW {
   uint32_t roff = 0, moff = 0;  // byte offsets of rec_planes[t][role*H][i] (relative to row 0) / rec_meta[t][i]
   uint8_t* ra = nullptr;   // act_log[t / 4][i]
   uint64_t quad = 0;
+  uint8_t* rh = nullptr;   // ACT 4 (MNK_ACT_U8P1): the bit plane of bit 8 behind the byte words, see mnk_rollout_lane.h
+  uint32_t hi4 = 0, hiw = 0, hfill = 0;
   uint32_t acc_done = 0, acc_win = 0, acc_white = 0;
 
   __device__ __forceinline__ RolloutPairW(const MnkGeom& g_, int64_t N_, int64_t i, uint32_t role_, uint64_t* rec_planes,
@@ -50,9 +52,13 @@ struct RolloutPairW {
       roff = ((uint32_t)i + role * (uint32_t)H * (uint32_t)N) * 8u;
       moff = (uint32_t)i * 4u;
     }
-    if (ACT) ra = (uint8_t*)act_log + i * 4 * ACT;
+    if (ACT) ra = (uint8_t*)act_log + i * 4 * (ACT == 2 ? 2 : 1);
 #pragma unroll
     for (int j = 0; j < H; ++j) valid[j] = role ? g.valid[H + j] : g.valid[j];  // g.valid is 0 past the board's last word
+  }
+
+  __device__ __forceinline__ void log_begin(void* act_log, int T, int64_t i) {
+    if constexpr (ACT == 4) rh = (uint8_t*)act_log + ((int64_t)((T + 3) >> 2) * N + i) * 4;
   }
 
   // 32-bit word `gw` of a plane in memory (u64[W][N]); 0 past the board's last word
@@ -154,12 +160,34 @@ struct RolloutPairW {
   }
 
   __device__ __forceinline__ void log_flush() {
+    if constexpr (ACT == 4) {  // low bytes as one word, bit 8 of the four actions into the bit plane (both lanes keep the
+      if (role == 0) *(uint32_t*)ra = (uint32_t)quad;  // cursors; the lower lane stores)
+      ra += N * 4;
+      quad = 0;
+      hiw |= hi4 << hfill;
+      hi4 = 0;
+      hfill += 4u;
+      if (hfill == 32u) {
+        if (role == 0) *(uint32_t*)rh = hiw;
+        rh += N * 4;
+        hiw = 0;
+        hfill = 0;
+      }
+      return;
+    }
     if (role == 0) {
       if (ACT == 1) *(uint32_t*)ra = (uint32_t)quad;
       if (ACT == 2) *(uint64_t*)ra = quad;
     }
     ra += N * 4 * ACT;
     quad = 0;
+  }
+
+  __device__ __forceinline__ void log_finish(int T) {
+    if (ACT && (T & 3)) log_flush();
+    if constexpr (ACT == 4) {
+      if (hfill && role == 0) *(uint32_t*)rh = hiw;
+    }
   }
 
   // uniform legal cell from one u32 (oracle/philox.py pick_legal): the action (same in both lanes) and the cell's
@@ -194,7 +222,11 @@ struct RolloutPairW {
   __device__ __forceinline__ void ply(uint32_t x, int field) {
     uint32_t hot[H];
     const int a = pick(x, hot);
-    if (ACT) {
+    if constexpr (ACT == 4) {
+      quad |= (uint64_t)((uint32_t)a & 0xFFu) << (8 * field);
+      hi4 |= ((uint32_t)a >> 8) << field;
+      if (field == 3) log_flush();
+    } else if (ACT) {
       quad |= (uint64_t)(uint32_t)a << (8 * ACT * field);
       if (field == 3) log_flush();
     }
@@ -244,6 +276,7 @@ k_rollout_random_pairw(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, i
   const int64_t i = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 1);  // env of this lane pair
   if (i < N) {
     RolloutPairW<NW, CN, CK, RECORD, ACT> L(g, N, i, role, rec_planes, rec_meta, act_log);
+    L.log_begin(act_log, T, i);
     L.load(planes, meta, i);
     const uint64_t env = (uint64_t)(env_id0 + i);
     int t = 0;
@@ -266,7 +299,7 @@ k_rollout_random_pairw(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, i
       for (int j = 0; j < 4; ++j) L.ply(hi[j], j);
     }
     for (; t < T; ++t, ++step) L.ply(mnk_rand_u32(seed, env, step, MNK_STREAM_MOVE), (int)(step & 3));
-    if (ACT && (T & 3)) L.log_flush();
+    L.log_finish(T);
     L.store(planes, meta, i);
     if (stats && role == 0) {
       const uint32_t len_sum = L.moves_in + (uint32_t)T - L.moves;
@@ -306,8 +339,11 @@ void mnk_launch_rollout_pairw(const MnkGeom& g, uint64_t* planes, uint32_t* meta
     else if (g.n == 13) MNK_PW(6, 13, 5, REC, ACTB);          \
     else MNK_PW(3, 9, 5, REC, ACTB);                          \
   } while (0)
-  // boards up to 256 cells log a byte per action; 19x19 = 361 needs two
-  if (rec && act_bytes == 1) MNK_PW_GEOM(true, 1);
+  // boards up to 256 cells log a byte per action; 19x19 = 361 needs two, or a byte and a bit (MNK_ACT_U8P1)
+  if (act_bytes == MNK_ACT_U8P1) {
+    if (rec) MNK_PW(12, 19, 5, true, 4);
+    else MNK_PW(12, 19, 5, false, 4);
+  } else if (rec && act_bytes == 1) MNK_PW_GEOM(true, 1);
   else if (rec && act_bytes == 2) MNK_PW_GEOM(true, 2);
   else if (rec) MNK_PW_GEOM(true, 0);
   else if (act_bytes == 1) MNK_PW_GEOM(false, 1);

@@ -19,7 +19,7 @@ ERR_NONE, ERR_ACTION_RANGE, ERR_ILLEGAL_MOVE = 0, 1, 2
 STEP_STRICT, STEP_AUTORESET = 1, 2
 LOGITS_F32, LOGITS_BF16 = 0, 1
 OBS_F32, OBS_BF16, OBS_U8 = 0, 1, 2
-ACT_U8, ACT_U16, ACT_BITS7 = 1, 2, 3
+ACT_U8, ACT_U16, ACT_BITS7, ACT_U8P1 = 1, 2, 3, 4
 COMM_ID_BYTES = 128
 SP_NEED_OPP, SP_WAS_RESET = 1, 2
 STREAM_MOVE, STREAM_OPP, STREAM_SIDE, STREAM_SAMPLE = 0, 1, 2, 3

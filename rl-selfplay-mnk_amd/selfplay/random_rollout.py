@@ -96,7 +96,8 @@ class RandomRollout:
 
     def alloc(self, steps: int, log_actions=False, with_state: bool = True) -> RolloutRecords:
         """Record buffers for ``steps`` plies.  ``log_actions``: False, True (the most compact format the board allows:
-        7 bits per action up to 128 cells) or one of ACT_U8 / ACT_U16 / ACT_BITS7; ``with_state``: the chunk-start
+        7 bits per action up to 128 cells, a byte and a bit above 256) or one of ACT_U8 / ACT_U16 / ACT_BITS7 /
+        ACT_U8P1; ``with_state``: the chunk-start
         planes / meta travel in the message too (a self-contained message), else the log alone."""
         env = self.env
         rec = RolloutRecords(
@@ -106,8 +107,7 @@ class RandomRollout:
         )
         if log_actions:
             fmt = action_log_format(env.max_moves) if log_actions is True else int(log_actions)
-            if fmt not in (ACT_U8, ACT_U16, ACT_BITS7) or (fmt == ACT_U8 and env.max_moves > 256) or \
-                    (fmt == ACT_BITS7 and env.max_moves > 128):
+            if not action_log_fits(fmt, env.max_moves):
                 raise ValueError(f"action-log format {fmt} does not fit a board of {env.max_moves} cells")
             rec.fmt = fmt
             rec.msg = torch.zeros(_msg_words(env.words, env.num_envs, steps, fmt, with_state), dtype=torch.int64,
@@ -137,21 +137,28 @@ class RandomRollout:
         return out if record else None
 
 
-ACT_U8, ACT_U16, ACT_BITS7 = 1, 2, 3  # include/mnk_hip.h MNK_ACT_*
+ACT_U8, ACT_U16, ACT_BITS7, ACT_U8P1 = 1, 2, 3, 4  # include/mnk_hip.h MNK_ACT_*
 
 
 def action_log_format(num_actions: int, compact: bool = True) -> int:
-    """The most compact log format a board of ``num_actions`` cells allows: 7 bits per action up to 128 cells (only with
-    ``compact``), one byte up to 256, two bytes beyond."""
+    """The most compact log format a board of ``num_actions`` cells allows: 7 bits per action up to 128 cells, one byte
+    up to 256, a byte and a bit beyond (without ``compact``: one byte up to 256 cells, two bytes beyond -- round 2's)."""
     if compact and num_actions <= 128:
         return ACT_BITS7
-    return ACT_U8 if num_actions <= 256 else ACT_U16
+    if num_actions <= 256:
+        return ACT_U8
+    return ACT_U8P1 if compact else ACT_U16
+
+
+def action_log_fits(fmt: int, num_actions: int) -> bool:
+    return fmt == ACT_U16 or (fmt == ACT_U8 and num_actions <= 256) or (fmt == ACT_BITS7 and num_actions <= 128) or \
+        (fmt == ACT_U8P1 and num_actions > 256)
 
 
 def action_log_words(fmt: int, steps: int) -> int:
     """32-bit words per env of a ``steps``-ply log (= mnk_action_log_words)"""
     q = (steps + 3) // 4
-    return {ACT_U8: q, ACT_U16: 2 * q, ACT_BITS7: (7 * q + 7) // 8}[fmt]
+    return {ACT_U8: q, ACT_U16: 2 * q, ACT_BITS7: (7 * q + 7) // 8, ACT_U8P1: q + (steps + 31) // 32}[fmt]
 
 
 def unpack_action_log(act: torch.Tensor, steps: int, fmt: Optional[int] = None) -> torch.Tensor:
@@ -166,6 +173,12 @@ def unpack_action_log(act: torch.Tensor, steps: int, fmt: Optional[int] = None) 
         lo = words[w]
         hi = words[torch.clamp(w + 1, max=words.shape[0] - 1)]
         return (((lo | (hi << 32)) >> sh.unsqueeze(1)) & 0x7F).to(torch.int64)
+    if fmt == ACT_U8P1:
+        q = (steps + 3) // 4
+        low = unpack_action_log(act[:q], steps, ACT_U8)
+        t = torch.arange(steps, device=act.device)
+        high = (act[q:].to(torch.int64)[t // 32] >> (t % 32).unsqueeze(1)) & 1
+        return low | (high << 8)
     bits = 8 if fmt == ACT_U8 else 16
     fields = [(act >> (bits * j)) & ((1 << bits) - 1) for j in range(4)]
     return torch.stack(fields, dim=1).reshape(-1, act.shape[1])[:steps].to(torch.int64)

@@ -81,10 +81,11 @@ def test_rollout_kernel_specialises_at_run_time_without_a_gpu(lib):
     """hiprtc compiles the rollout kernel for boards that have no ahead-of-time specialisation (csrc/mnk_jit.hip);
     compiling needs no GPU, so the build container checks that the embedded headers still compile for gfx950."""
     handle = lib.load()
-    for (m, n, k, rec, act) in [(12, 12, 5, 1, 0), (7, 9, 7, 0, 1), (22, 22, 10, 1, 2), (11, 11, 5, 1, 3)]:
+    for (m, n, k, rec, act) in [(12, 12, 5, 1, 0), (7, 9, 7, 0, 1), (22, 22, 10, 1, 2), (11, 11, 5, 1, 3), (22, 22, 10, 1, 4)]:
         size = handle.mnk_jit_compile_rollout(m, n, k, rec, act)
         assert size > 4096, (handle.mnk_jit_last_error() or b"").decode()
     assert handle.mnk_jit_compile_rollout(30, 30, 5, 1, 0) == -2   # MNK_EGEOM: beyond the packed layout
     assert handle.mnk_jit_compile_rollout(13, 13, 5, 1, 3) == -1   # MNK_EINVAL: 169 cells do not fit the 7-bit log
-    assert handle.mnk_jit_compile_rollout(9, 9, 5, 1, 4) == -1     # MNK_EINVAL: no such log format
-    assert [handle.mnk_action_log_words(f, 256) for f in (1, 2, 3, 4)] == [64, 128, 56, 0]
+    assert handle.mnk_jit_compile_rollout(9, 9, 5, 1, 4) == -1     # MNK_EINVAL: the byte + bit log is for boards above 256 cells
+    assert handle.mnk_jit_compile_rollout(9, 9, 5, 1, 5) == -1     # MNK_EINVAL: no such log format
+    assert [handle.mnk_action_log_words(f, 256) for f in (1, 2, 3, 4, 5)] == [64, 128, 56, 72, 0]

@@ -103,6 +103,27 @@ def test_sharded_rollout_gathers_to_the_single_process_result(tmp_path, m, n, k,
         assert np.array_equal(got["stats"], stats)
 
 
+def test_action_log_formats_round_trip_between_the_oracle_and_the_host_code():
+    """Every log format: the oracle's numpy packing of random actions, read back by the product's torch unpacker
+    (``selfplay.random_rollout.unpack_action_log``), gives the actions; word counts agree with the library's."""
+    entry._ensure_path()
+    import mnk_hip
+    from oracle.rollout import decode_action_log, encode_action_log
+    from selfplay.random_rollout import ACT_BITS7, ACT_U8, ACT_U8P1, ACT_U16, action_log_words, unpack_action_log
+
+    rng = np.random.default_rng(3)
+    lib = mnk_hip.load()
+    for fmt, cells in ((ACT_U8, 256), (ACT_U16, 484), (ACT_BITS7, 128), (ACT_U8P1, 484)):
+        for steps in (1, 3, 4, 5, 31, 32, 33, 100, 256):
+            acts = rng.integers(0, cells, (steps, 7))
+            log = encode_action_log(acts, fmt)
+            assert np.array_equal(decode_action_log(log, steps, fmt), acts)
+            as_torch = torch.from_numpy(log.view(np.int64 if fmt == ACT_U16 else np.int32).copy())
+            assert torch.equal(unpack_action_log(as_torch, steps, fmt), torch.from_numpy(acts)), (fmt, steps)
+            words = log.shape[0] * (2 if fmt == ACT_U16 else 1)
+            assert words == action_log_words(fmt, steps) == lib.mnk_action_log_words(fmt, steps), (fmt, steps)
+
+
 def test_gather_is_identity_for_one_rank(tmp_path):
     entry._ensure_path()
     from selfplay.random_rollout import RolloutRecords, gather_records

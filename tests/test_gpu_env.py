@@ -444,12 +444,13 @@ def test_action_log_replay_rebuilds_the_records(hip, m, n, k, nenv, steps, lane_
     cells), in a self-contained message (chunk-start state + log) or alone (the receiver keeps the replay state).
     The log == the oracle's packing of the recorded actions; mnk_replay_actions on it == the records the rollout
     wrote (bit for bit) == the oracle's replay of the same actions; a second chunk checks that the state carried over."""
-    from selfplay.random_rollout import (ACT_BITS7, ACT_U8, ACT_U16, GatheredLogs, ReplayState, action_log_format,
-                                         action_log_words, replay_shard, unpack_action_log)
+    from selfplay.random_rollout import (ACT_BITS7, ACT_U8, ACT_U8P1, ACT_U16, GatheredLogs, ReplayState, action_log_fits,
+                                         action_log_format, action_log_words, replay_shard, unpack_action_log)
 
     c = m * n
-    assert action_log_format(c) == (ACT_BITS7 if c <= 128 else ACT_U8 if c <= 256 else ACT_U16)
-    formats = [f for f in (ACT_U8, ACT_U16, ACT_BITS7) if (f != ACT_U8 or c <= 256) and (f != ACT_BITS7 or c <= 128)]
+    assert action_log_format(c) == (ACT_BITS7 if c <= 128 else ACT_U8 if c <= 256 else ACT_U8P1)
+    assert action_log_format(c, compact=False) == (ACT_U8 if c <= 256 else ACT_U16)
+    formats = [f for f in (ACT_U8, ACT_U16, ACT_BITS7, ACT_U8P1) if action_log_fits(f, c)]
     oracle_records = None
     for fmt in formats:
         for with_state in (True, False):
@@ -487,8 +488,9 @@ def test_action_log_replay_rebuilds_the_records(hip, m, n, k, nenv, steps, lane_
                 oracle_records = [oracle_replay(ora, (meta & 0xFFFF).astype(np.int64)) for _, meta in got]
             for (planes, meta), (wp, wm) in zip(got, oracle_records):
                 assert np.array_equal(planes, wp) and np.array_equal(meta, wm), (fmt, with_state)
-    if len(formats) == 3:  # 0.875 B per env-step against 1 B
-        assert action_log_words(ACT_BITS7, 256) * 4 == 224 and action_log_words(ACT_U8, 256) * 4 == 256
+    # 0.875 B per env-step against 1 B up to 128 cells; 1.125 B against 2 B above 256
+    assert action_log_words(ACT_BITS7, 256) * 4 == 224 and action_log_words(ACT_U8, 256) * 4 == 256
+    assert action_log_words(ACT_U8P1, 256) * 4 == 288 and action_log_words(ACT_U16, 256) * 4 == 512
     with pytest.raises(ValueError):
         hip.Rollout(hip.Env(13, 13, 5, 4, device=DEV)).alloc(8, log_actions=ACT_BITS7)  # 169 cells do not fit 7 bits
 

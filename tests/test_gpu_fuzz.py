@@ -214,7 +214,8 @@ def test_rollout_and_log_fuzz(hip, seed):
     k = min(k, m, n)
     nenv = int(rng.choice([1, 3, 64, 65, 129, 300]))
     c = m * n
-    fmts = [hip.rollout.ACT_U16] + ([hip.rollout.ACT_U8] if c <= 256 else []) + ([hip.rollout.ACT_BITS7] if c <= 128 else [])
+    fmts = [f for f in (hip.rollout.ACT_U16, hip.rollout.ACT_U8, hip.rollout.ACT_BITS7, hip.rollout.ACT_U8P1)
+            if hip.rollout.action_log_fits(f, c)]
     saved = os.environ.get("MNK_JIT")
     os.environ["MNK_JIT"] = str(seed % 2)  # both kernels for boards without a built-in variant
     hip.lib.reload_config()

@@ -8,7 +8,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "rl-selfplay-mnk_amd")]
 import torch  # noqa: E402
 
 from env.torch_vector_mnk_env import TorchVectorMnkEnv  # noqa: E402
-from selfplay.random_rollout import ACT_BITS7, ACT_U8, ACT_U16, RandomRollout  # noqa: E402
+from selfplay.random_rollout import ACT_BITS7, ACT_U8, ACT_U8P1, ACT_U16, RandomRollout, action_log_fits  # noqa: E402
 
 board = sys.argv[1] if len(sys.argv) > 1 else "9x9x5"
 nenv = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
@@ -18,10 +18,10 @@ roll = RandomRollout(env, seed=0)
 T = 256
 for _ in range(200):
     roll.run(T, record=False)
-names = {0: "no log", ACT_U8: "u8", ACT_U16: "u16", ACT_BITS7: "7-bit"}
+names = {0: "no log", ACT_U8: "u8", ACT_U16: "u16", ACT_BITS7: "7-bit", ACT_U8P1: "u8+1bit"}
 for rep in range(2):
-    for fmt in (0, ACT_U8, ACT_U16, ACT_BITS7):
-        if (fmt == ACT_U8 and m * n > 256) or (fmt == ACT_BITS7 and m * n > 128):
+    for fmt in (0, ACT_U8, ACT_U16, ACT_BITS7, ACT_U8P1):
+        if fmt and not action_log_fits(fmt, m * n):
             continue
         buf = roll.alloc(T, log_actions=fmt, with_state=False) if fmt else roll.alloc(T)
         for _ in range(20):
