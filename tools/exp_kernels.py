@@ -58,6 +58,8 @@ def main(m=9, n=9, k=5, N=65536):
     report("step (no outputs)", timeit(with_restore(st(None, None))) - us_copy, N * (8 + S + 8 * W + 4 + 5), N)
     report("step + mask  [B_step]", timeit(with_restore(st(mask, None))) - us_copy, N * (8 + S + 8 * W + 4 + 5 + C), N)
     report("step + mask + obs", timeit(with_restore(st(mask, obs))) - us_copy, N * (8 + S + 8 * W + 4 + 5 + C + 8 * C), N)
+    report("step_random + mask (one launch per ply)", timeit(with_restore(lambda: env.step_random_into(rew, done, mask, seed=1, step=7))) - us_copy,
+           N * (S + 8 * W + 4 + 5 + C), N)
     report("observe (obs+mask)", timeit(lambda: env.observe_into(obs, mask)), N * (S - 4 + 9 * C), N)
     report("observe (mask only)", timeit(lambda: env.observe_into(None, mask)), N * (S - 4 + C), N)
     report("reset_mask", timeit(lambda: env.reset_mask_(done)), N * 1, N)

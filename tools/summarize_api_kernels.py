@@ -65,12 +65,16 @@ def main(d):
         if not name.startswith("k_"):
             continue
         key, what, nbytes = name, None, None
-        if name.startswith("k_step_full<"):
+        if name.startswith("k_step_full<") and name.endswith("true>"):
+            big = "<12, 19, 5" in name
+            nbytes = (N19 if big else N9) * (b_step(S19 if big else S9, W19 if big else W9, C19 if big else C9, True, False) - 8)
+            key, what = f"{name} (mnk_step_random) + legal mask", "state in; draw, mover plane, meta, reward, done, mask out (no action read)"
+        elif name.startswith("k_step_full<"):
             block = seen[name] // 55  # exp_kernels.py: 55 consecutive dispatches per output set, in STEP_SETS order
             seen[name] += 1
             if block < len(STEP_SETS):
                 label, mask, obs = STEP_SETS[block]
-                big = "<12, 19, 5>" in name
+                big = "<12, 19, 5" in name
                 nbytes = (N19 if big else N9) * b_step(S19 if big else S9, W19 if big else W9, C19 if big else C9, mask, obs)
                 key, what = f"{name} {label}", "action + state in; mover plane, meta, reward, done" + \
                     (", mask" if mask else "") + (", obs" if obs else "") + " out"

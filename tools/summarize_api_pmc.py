@@ -35,7 +35,7 @@ def main(fd, wd):
         rd = sum(fetch.get(name, [0])) / max(len(fetch.get(name, [0])), 1) * 1024 * 2 / 1e6
         wr = sum(write.get(name, [0])) / max(len(write.get(name, [0])), 1) * 1024 / 1e6
         alg = BYTES.get(name, (None, ""))[0]
-        if name.startswith("k_step_full<3, 9, 5>"):
+        if name.startswith("k_step_full<3, 9, 5, false"):
             alg = N9 * b_step(S9, W9, C9, True, True)
         if name.startswith("k_observe<3, 9, 5>"):
             alg = N9 * (32 + 9 * C9)
