@@ -108,3 +108,63 @@ def test_exchange_step_on_the_rccl_backend():
     out = subprocess.run([sys.executable, "-c", _NCCL_CHILD % {"root": ROOT}], env=env, capture_output=True,
                          text=True, timeout=300)
     assert "NCCL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+_TWO_RANK_CHILD = r"""
+import os, sys
+sys.path[:0] = [%(root)r, os.path.join(%(root)r, "rl-selfplay-mnk_amd")]
+import torch, torch.distributed as dist
+from env.torch_vector_mnk_env import TorchVectorMnkEnv
+from selfplay.random_rollout import KeyframedLogs, RandomRollout, gather_action_logs, gather_records
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+m, n, k, nenv, chunk, every = %(m)d, %(n)d, %(k)d, 320, 24, 3
+env = TorchVectorMnkEnv(m, n, k, nenv, device="cuda:0")
+roll = RandomRollout(env, seed=9, env_id0=rank * nenv)          # the shard's global env ids key the RNG
+history = KeyframedLogs(m, n, k)
+truth = []
+for c in range(7):
+    key = c %% every == 0
+    rec = roll.alloc(chunk, log_actions=True, with_state=key)
+    roll.run(chunk, out=rec)
+    history.push(gather_action_logs(rec))                       # the exchange step: ONE all-gather of the message
+    full = gather_records(rec)                                   # ground truth: every shard's records themselves
+    truth = [full] if key else truth + [full]
+    for shard in range(world):                                   # rebuild EVERY shard's records of EVERY held chunk
+        for j, want in enumerate(truth):
+            got = history.rebuild(shard, j)
+            cols = slice(shard * nenv, (shard + 1) * nenv)
+            assert torch.equal(got.planes, want.planes[:, :, cols]) and torch.equal(got.meta, want.meta[:, cols]), (c, shard, j)
+# and the sharded run as a whole equals one process with all the envs
+if rank == 0:
+    whole = RandomRollout(TorchVectorMnkEnv(m, n, k, world * nenv, device="cuda:0"), seed=9)
+    for c in range(7):
+        last = whole.run(chunk)
+    assert torch.equal(last.planes, truth[-1].planes) and torch.equal(last.meta, truth[-1].meta)
+dist.barrier()
+dist.destroy_process_group()
+print("RANK_OK", rank)
+"""
+
+
+@pytest.mark.parametrize("m,n,k", [(9, 9, 5), (19, 19, 5)])
+def test_two_ranks_exchange_keyframed_logs_and_rebuild_each_others_records(m, n, k):
+    """Two rank processes (gloo rendezvous and transport; both on this box's one GPU), each rolling out its own env
+    shard: every chunk's message is all-gathered (a keyframe every third chunk, the log alone otherwise; the 7-bit
+    stream at 9x9, the byte + bit log at 19x19), and every rank rebuilds EVERY shard's records of every chunk held
+    since the last keyframe -- equal to the records that shard wrote itself (all-gathered as ground truth), and the
+    two shards together equal a single process that holds all the envs."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _TWO_RANK_CHILD % {"root": ROOT, "m": m, "n": n, "k": k}], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for rank, (out, err) in enumerate(outs):
+        assert f"RANK_OK {rank}" in out, out[-2000:] + err[-4000:]
