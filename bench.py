@@ -388,7 +388,6 @@ def selfplay_object(m, n, k, nenv, seed, dev, steps=64):
     buf = RolloutBuffer(steps, nenv, (2, m, n), c, device=str(dev))
     roll = GraphedRollout(wrap, buf, None, seed=seed + 2)
     roll.run()
-    before = env._meta >> 1
     torch.cuda.synchronize(dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

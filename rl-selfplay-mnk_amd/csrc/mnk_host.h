@@ -75,30 +75,31 @@ struct MnkConfig {
 };
 enum { MNK_FORM_NONE = 0, MNK_FORM_LANE, MNK_FORM_PAIR, MNK_FORM_PAIRW, MNK_FORM_WS2, MNK_FORM_WS4 };
 
-inline const MnkConfig& mnk_config(bool reload = false) {
-  static MnkConfig cfg;
-  static bool loaded = false;
-  if (!loaded || reload) {
-    MnkConfig c;
-    if (const char* v = getenv("MNK_ROLLOUT_PAIR")) c.pair_override = atoi(v) != 0 ? 1 : 0;
-    if (const char* v = getenv("MNK_ROLLOUT_FORM")) {
-      static const char* names[] = {"", "lane", "pair", "pairw", "ws2", "ws4"};
-      for (int f = 1; f <= 5; ++f)
-        if (!strcmp(v, names[f])) c.form = f;
-    }
-    if (const char* v = getenv("MNK_JIT")) c.jit = atoi(v) != 0 ? 1 : 0;
-    if (const char* v = getenv("MNK_ROLLOUT_SADDR")) c.saddr_off = atoi(v) == 0;
-    if (const char* v = getenv("MNK_EMIT_ENVS")) {
-      const int t = atoi(v);
-      c.emit_envs = (t == 16 || t == 32 || t == 64 || t == 128) ? t : 0;
-    }
-    if (const char* v = getenv("MNK_EMIT_THREADS")) {
-      const int t = atoi(v);
-      c.emit_threads = (t == 64 || t == 128 || t == 256) ? t : 0;  // anything else would break the launch bounds
-    }
-    cfg = c;
-    loaded = true;
+inline MnkConfig mnk_read_config() {
+  MnkConfig c;
+  if (const char* v = getenv("MNK_ROLLOUT_PAIR")) c.pair_override = atoi(v) != 0 ? 1 : 0;
+  if (const char* v = getenv("MNK_ROLLOUT_FORM")) {
+    static const char* names[] = {"", "lane", "pair", "pairw", "ws2", "ws4"};
+    for (int f = 1; f <= 5; ++f)
+      if (!strcmp(v, names[f])) c.form = f;
   }
+  if (const char* v = getenv("MNK_JIT")) c.jit = atoi(v) != 0 ? 1 : 0;
+  if (const char* v = getenv("MNK_ROLLOUT_SADDR")) c.saddr_off = atoi(v) == 0;
+  if (const char* v = getenv("MNK_EMIT_ENVS")) {
+    const int t = atoi(v);
+    c.emit_envs = (t == 16 || t == 32 || t == 64 || t == 128) ? t : 0;
+  }
+  if (const char* v = getenv("MNK_EMIT_THREADS")) {
+    const int t = atoi(v);
+    c.emit_threads = (t == 64 || t == 128 || t == 256) ? t : 0;  // anything else would break the launch bounds
+  }
+  return c;
+}
+
+// (the first call initialises the function-local static: thread-safe; a reload is the caller's to serialise)
+inline const MnkConfig& mnk_config(bool reload = false) {
+  static MnkConfig cfg = mnk_read_config();
+  if (reload) cfg = mnk_read_config();
   return cfg;
 }
 
