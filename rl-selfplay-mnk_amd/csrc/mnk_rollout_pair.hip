@@ -14,6 +14,32 @@
 // instructions per env, so it wins exactly while both lanes of every env fit one wave per SIMD (2N <= 65 536
 // lanes) and the launcher uses it only up to 32 768 envs.
 
+// the T plies of one lane pair (FAST: see mnk_rollout_lane.h -- every game of the wave consistent)
+template <bool FAST, typename Lane>
+__device__ __forceinline__ void pair_plies(Lane& L, int T, uint64_t seed, uint64_t step0, uint64_t env, uint32_t role) {
+  int t = 0;
+  uint64_t step = step0;
+  // unshared Philox until the step counter sits on a multiple of 8 (two blocks)
+  for (; t < T && (step & 7); ++t, ++step)
+    L.template ply<FAST>(mnk_rand_u32(seed, env, step, MNK_STREAM_MOVE), (int)(step & 3));
+  for (; t + 8 <= T; t += 8, step += 8) {
+    // lane `role` computes block (step/4 + role); the partner's four words arrive by DPP
+    const Philox4 mine = mnk_rng_block(seed, env, (step >> 2) + role, MNK_STREAM_MOVE);
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t other = pair_swap(mine.v[j]);
+      lo[j] = role ? other : mine.v[j];  // block step/4
+      hi[j] = role ? mine.v[j] : other;  // block step/4 + 1
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) L.template ply<FAST>(lo[j], j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) L.template ply<FAST>(hi[j], j);
+  }
+  for (; t < T; ++t, ++step) L.template ply<FAST>(mnk_rand_u32(seed, env, step, MNK_STREAM_MOVE), (int)(step & 3));
+}
+
 template <int NW, int CN, int CK, bool RECORD, int ACT>
 __global__ void __launch_bounds__(64)
 k_rollout_random_pair(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed, uint64_t step0,
@@ -28,26 +54,15 @@ k_rollout_random_pair(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, in
     RolloutLane<NW, CN, CK, RECORD, ACT, true> L(g, N, i, rec_planes, rec_meta, act_log, role);
     L.load(planes, meta, i);
     const uint64_t env = (uint64_t)(env_id0 + i);
-    int t = 0;
-    uint64_t step = step0;
-    // unshared Philox until the step counter sits on a multiple of 8 (two blocks)
-    for (; t < T && (step & 7); ++t, ++step) L.ply(mnk_rand_u32(seed, env, step, MNK_STREAM_MOVE), (int)(step & 3));
-    for (; t + 8 <= T; t += 8, step += 8) {
-      // lane `role` computes block (step/4 + role); the partner's four words arrive by DPP
-      const Philox4 mine = mnk_rng_block(seed, env, (step >> 2) + role, MNK_STREAM_MOVE);
-      uint32_t lo[4], hi[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t other = pair_swap(mine.v[j]);
-        lo[j] = role ? other : mine.v[j];  // block step/4
-        hi[j] = role ? mine.v[j] : other;  // block step/4 + 1
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) L.ply(lo[j], j);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) L.ply(hi[j], j);
+    // both lanes of a pair hold the whole board: the consistency test of the one-lane form applies as it is.  Small
+    // boards only (what the launcher uses this form for: 3x3 and 9x9); the larger ones keep the one general loop.
+    constexpr bool TRY_FAST = NW <= 3;
+    if (TRY_FAST && __builtin_amdgcn_ballot_w64(!L.consistent()) == 0) {
+      pair_plies<true>(L, T, seed, step0, env, role);
+      L.finish_fast();
+    } else {
+      pair_plies<false>(L, T, seed, step0, env, role);
     }
-    for (; t < T; ++t, ++step) L.ply(mnk_rand_u32(seed, env, step, MNK_STREAM_MOVE), (int)(step & 3));
     if (ACT && (T & 3)) L.log_flush();
     L.store(planes, meta, i);  // lane `role` stores plane `role`; the meta word is written by both
     if (stats && role == 0) {

@@ -192,14 +192,18 @@ struct RolloutPairW {
 
   // uniform legal cell from one u32 (oracle/philox.py pick_legal): the action (same in both lanes) and the cell's
   // bit as a one-hot string over this lane's words (all zero in the lane that does not hold it)
-  __device__ __forceinline__ int pick(uint32_t x, uint32_t (&hot)[H]) const {
+  // FAST: every game of the wave is consistent (stones == plies counted < C, mnk_rollout_lane.h): no full-board branch,
+  // and `nlegal` (the pair's legal-cell count) stands in for the ply counter
+  template <bool FAST = false>
+  __device__ __forceinline__ int pick(uint32_t x, uint32_t (&hot)[H], uint32_t& nlegal) const {
     uint32_t legal[H];
 #pragma unroll
     for (int j = 0; j < H; ++j) legal[j] = ~(cur[j] | oth[j]) & valid[j];
     uint32_t mine_n = (uint32_t)bs_popcount<H>(legal);
     uint32_t other_n = partner(mine_n);
     uint32_t n = mine_n + other_n;
-    if (__builtin_amdgcn_ballot_w64(n == 0) != 0) {  // full board (poked states only): any cell, like RandomPolicy's 1e-8 guard
+    nlegal = n;
+    if (!FAST && __builtin_amdgcn_ballot_w64(n == 0) != 0) {  // full board (poked states only): any cell, like RandomPolicy's 1e-8 guard
       const bool full = n == 0;
 #pragma unroll
       for (int j = 0; j < H; ++j) legal[j] = full ? valid[j] : legal[j];
@@ -219,9 +223,11 @@ struct RolloutPairW {
     return (int)(holds ? a_here : a_there);
   }
 
+  template <bool FAST = false>
   __device__ __forceinline__ void ply(uint32_t x, int field) {
     uint32_t hot[H];
-    const int a = pick(x, hot);
+    uint32_t nlegal;
+    const int a = pick<FAST>(x, hot, nlegal);
     if constexpr (ACT == 4) {
       quad |= (uint64_t)((uint32_t)a & 0xFFu) << (8 * field);
       hi4 |= ((uint32_t)a >> 8) << field;
@@ -239,11 +245,11 @@ struct RolloutPairW {
     }
 #pragma unroll
     for (int j = 0; j < H; ++j) cur[j] |= hot[j];                         // env:68
-    ++moves;                                                              // :69
+    if (!FAST) ++moves;                                                   // :69
     uint32_t hit = run_bits<1>() | run_bits<CN + 1>() | run_bits<CN + 2>() | run_bits<CN>();  // :71, this lane's words
     hit |= partner(hit);
     const uint32_t win = hit ? 1u : 0u;
-    const uint32_t done = win | (moves >= (uint32_t)g.C ? 1u : 0u);       // :72-73
+    const uint32_t done = win | ((FAST ? nlegal == 1u : moves >= (uint32_t)g.C) ? 1u : 0u);  // :72-73
     if (RECORD) {
       if (role == 0)
         __builtin_nontemporal_store((uint32_t)a | (win << MNK_REC_REWARD_SHIFT) | (done << MNK_REC_DONE_BIT) | (side << MNK_REC_SIDE_BIT),
@@ -260,9 +266,50 @@ struct RolloutPairW {
       oth[j] = done ? 0u : c;
     }
     side = done ? 0u : (side ^ 1u);
-    moves = done ? 0u : moves;
+    if (!FAST) moves = done ? 0u : moves;
   }
+
+  // stones of the pair's board (both lanes get the sum)
+  __device__ __forceinline__ uint32_t stones() const {
+    uint32_t occ[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) occ[j] = cur[j] | oth[j];
+    const uint32_t mine = (uint32_t)bs_popcount<H>(occ);
+    return mine + partner(mine);
+  }
+  __device__ __forceinline__ bool consistent() const { return stones() == moves && moves < (uint32_t)g.C; }
+  __device__ __forceinline__ void finish_fast() { moves = stones(); }
 };
+
+#ifndef MNK_PAIRW_FAST
+#define MNK_PAIRW_FAST 1  // (0: build without the FAST loop, for A/B timing)
+#endif
+
+// the T plies of one lane pair
+template <bool FAST, typename Lane>
+__device__ __forceinline__ void pairw_plies(Lane& L, int T, uint64_t seed, uint64_t step0, uint64_t env, uint32_t role) {
+  int t = 0;
+  uint64_t step = step0;
+  // unshared Philox until the step counter sits on a multiple of 8 (two blocks)
+  for (; t < T && (step & 7); ++t, ++step)
+    L.template ply<FAST>(mnk_rand_u32(seed, env, step, MNK_STREAM_MOVE), (int)(step & 3));
+  for (; t + 8 <= T; t += 8, step += 8) {
+    // lane `role` computes block (step/4 + role); the partner's four words arrive by DPP
+    const Philox4 mine = mnk_rng_block(seed, env, (step >> 2) + role, MNK_STREAM_MOVE);
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t other = partner(mine.v[j]);
+      lo[j] = role ? other : mine.v[j];  // block step/4
+      hi[j] = role ? mine.v[j] : other;  // block step/4 + 1
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) L.template ply<FAST>(lo[j], j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) L.template ply<FAST>(hi[j], j);
+  }
+  for (; t < T; ++t, ++step) L.template ply<FAST>(mnk_rand_u32(seed, env, step, MNK_STREAM_MOVE), (int)(step & 3));
+}
 
 template <int NW, int CN, int CK, bool RECORD, int ACT>
 __global__ void __launch_bounds__(64)
@@ -279,26 +326,15 @@ k_rollout_random_pairw(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, i
     L.log_begin(act_log, T, i);
     L.load(planes, meta, i);
     const uint64_t env = (uint64_t)(env_id0 + i);
-    int t = 0;
-    uint64_t step = step0;
-    // unshared Philox until the step counter sits on a multiple of 8 (two blocks)
-    for (; t < T && (step & 7); ++t, ++step) L.ply(mnk_rand_u32(seed, env, step, MNK_STREAM_MOVE), (int)(step & 3));
-    for (; t + 8 <= T; t += 8, step += 8) {
-      // lane `role` computes block (step/4 + role); the partner's four words arrive by DPP
-      const Philox4 mine = mnk_rng_block(seed, env, (step >> 2) + role, MNK_STREAM_MOVE);
-      uint32_t lo[4], hi[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t other = partner(mine.v[j]);
-        lo[j] = role ? other : mine.v[j];  // block step/4
-        hi[j] = role ? mine.v[j] : other;  // block step/4 + 1
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) L.ply(lo[j], j);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) L.ply(hi[j], j);
+    // every game of this wave consistent (any state the env produced itself): the loop without the full-board branch
+    // and the ply counter (mnk_rollout_lane.h, FAST); a wave with a poked state plays the general loop, same results.
+    // This form runs small batches, where the instruction count is the bound: it pays on every board it is built for.
+    if (MNK_PAIRW_FAST && __builtin_amdgcn_ballot_w64(!L.consistent()) == 0) {
+      pairw_plies<true>(L, T, seed, step0, env, role);
+      L.finish_fast();
+    } else {
+      pairw_plies<false>(L, T, seed, step0, env, role);
     }
-    for (; t < T; ++t, ++step) L.ply(mnk_rand_u32(seed, env, step, MNK_STREAM_MOVE), (int)(step & 3));
     L.log_finish(T);
     L.store(planes, meta, i);
     if (stats && role == 0) {
