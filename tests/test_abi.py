@@ -89,3 +89,14 @@ def test_rollout_kernel_specialises_at_run_time_without_a_gpu(lib):
     assert handle.mnk_jit_compile_rollout(9, 9, 5, 1, 4) == -1     # MNK_EINVAL: the byte + bit log is for boards above 256 cells
     assert handle.mnk_jit_compile_rollout(9, 9, 5, 1, 5) == -1     # MNK_EINVAL: no such log format
     assert [handle.mnk_action_log_words(f, 256) for f in (1, 2, 3, 4, 5)] == [64, 128, 56, 72, 0]
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/mnk_hip.h is a C ABI: it must compile as C99 (a cgo / JNI / plain C host includes it as is) and as C++."""
+    import subprocess
+
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "mnk_hip.h"\nint main(void) { return MNK_ABI_VERSION == 4 ? 0 : 1; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)], check=True)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)], check=True)
