@@ -124,6 +124,44 @@ def test_action_log_formats_round_trip_between_the_oracle_and_the_host_code():
             assert words == action_log_words(fmt, steps) == lib.mnk_action_log_words(fmt, steps), (fmt, steps)
 
 
+def test_exchange_message_layout_is_a_partition_of_the_buffer():
+    """The one flat int64 message that is all-gathered -- [planes0 |] log [| meta0] -- for every log format, with and
+    without the chunk-start state, odd env counts and ragged chunk lengths: the views tile the buffer without overlap
+    (writing a distinct value through each view and reading the flat buffer back), every part starts on an 8-byte
+    boundary, and the leading (rank) dimension of a gathered buffer is carried through."""
+    entry._ensure_path()
+    from selfplay.random_rollout import (ACT_BITS7, ACT_U8, ACT_U8P1, ACT_U16, _msg_layout, _msg_views, _msg_words,
+                                         action_log_words)
+
+    rng = np.random.default_rng(11)
+    for fmt in (ACT_U8, ACT_U16, ACT_BITS7, ACT_U8P1):
+        for with_state in (True, False):
+            for _ in range(6):
+                words, nenv, steps = int(rng.integers(1, 7)), int(rng.integers(1, 70)), int(rng.integers(1, 300))
+                total = _msg_words(words, nenv, steps, fmt, with_state)
+                assert total == sum(_msg_layout(words, nenv, steps, fmt, with_state))
+                for lead in ((), (3,)):
+                    msg = torch.zeros(lead + (total,), dtype=torch.int64)
+                    planes0, act, meta0 = _msg_views(msg, words, nenv, steps, fmt, with_state)
+                    assert (planes0 is not None) == with_state == (meta0 is not None)
+                    if fmt == ACT_U16:
+                        assert act.dtype == torch.int64 and act.shape == lead + ((steps + 3) // 4, nenv)
+                    else:
+                        assert act.dtype == torch.int32 and act.shape == lead + (action_log_words(fmt, steps), nenv)
+                    act.fill_(-1)
+                    flat_bytes = msg.view(torch.uint8).reshape(lead + (-1,))
+                    n_planes, n_act, n_meta = _msg_layout(words, nenv, steps, fmt, with_state)
+                    lo, hi = n_planes * 8, n_planes * 8 + act.numel() // max(1, int(np.prod(lead))) * act.element_size()
+                    assert bool((flat_bytes[..., lo:hi] == 255).all()) and int((flat_bytes == 255).sum()) == act.numel() * act.element_size()
+                    if with_state:
+                        planes0.fill_(0x0101010101010101)
+                        meta0.fill_(0x02020202)
+                        assert planes0.shape == lead + (2, words, nenv) and meta0.shape == lead + (nenv,)
+                        assert int((flat_bytes == 1).sum()) == planes0.numel() * 8 and int((flat_bytes == 2).sum()) == meta0.numel() * 4
+                        assert bool((flat_bytes[..., :lo] == 1).all())
+                        assert bool((flat_bytes[..., (n_planes + n_act) * 8:(n_planes + n_act) * 8 + nenv * 4] == 2).all())
+
+
 def test_gather_is_identity_for_one_rank(tmp_path):
     entry._ensure_path()
     from selfplay.random_rollout import RolloutRecords, gather_records
