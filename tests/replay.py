@@ -17,7 +17,10 @@ def golden_files(golden_dir, prefix):
 
 
 def _np(t):
-    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+    if isinstance(t, torch.Tensor):
+        t = t.detach().cpu()
+        return (t.float() if t.dtype == torch.bfloat16 else t).numpy()  # (numpy has no bfloat16; cells are 0 / 1)
+    return np.asarray(t)
 
 
 def dense_boards(env):
@@ -54,7 +57,8 @@ def replay_env_log(env, log):
             obs, rew, done = env.step_subset(acts[idx], idx)
         where = f"op {t}"
         assert rew.dtype == torch.float32 and done.dtype == torch.bool
-        assert obs["observation"].dtype == torch.float32 and obs["action_mask"].dtype == torch.bool
+        # float32 like the reference's, unless the env was built with one of the opt-in narrow observation dtypes
+        assert obs["observation"].dtype == getattr(env, "obs_dtype", torch.float32) and obs["action_mask"].dtype == torch.bool
         assert np.array_equal(_np(rew), log["rewards"][t].astype(np.float32)), f"{where}: rewards differ"
         assert np.array_equal(_np(done), log["dones"][t]), f"{where}: dones differ"
         assert np.array_equal(pack_cells(_np(obs["action_mask"]), m, n), log["mask"][t]), f"{where}: mask differs"

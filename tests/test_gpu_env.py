@@ -49,6 +49,16 @@ def test_env_oplog_matches_reference(hip, golden_dir, idx):
     replay_env_log(hip.Env(m, n, k, nenv, device=DEV), log)
 
 
+@pytest.mark.parametrize("obs_dtype", [torch.bfloat16, torch.uint8])
+@pytest.mark.parametrize("idx", [0, 3, 5, 8, 10])
+def test_env_oplog_matches_reference_with_narrow_observations(hip, golden_dir, idx, obs_dtype):
+    """The same reference op-logs on an env that hands out bf16 / u8 observations (ABI v4, opt-in): the cells the
+    reference recorded, in the narrow dtype."""
+    log = np.load(golden_files(golden_dir, "env_")[idx])
+    m, n, k, nenv, _ = (int(v) for v in log["geom"])
+    replay_env_log(hip.Env(m, n, k, nenv, device=DEV, obs_dtype=obs_dtype), log)
+
+
 @pytest.mark.parametrize("name", sorted(SCENARIOS))
 def test_edge_scenarios_match_reference(hip, golden_dir, name):
     """G4: poked positions, answers recorded from the reference."""

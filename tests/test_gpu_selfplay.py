@@ -55,6 +55,31 @@ def test_selfplay_trace_matches_reference(hip, golden_dir, idx):
     replay_selfplay_trace(wrap, log, lambda w, sides: w.force_sides(torch.from_numpy(sides.astype(np.int64))))
 
 
+@pytest.mark.parametrize("obs_dtype", [torch.bfloat16, torch.uint8])
+@pytest.mark.parametrize("idx", [0, 2, 4, 6])
+def test_selfplay_trace_matches_reference_with_narrow_observations(hip, golden_dir, idx, obs_dtype):
+    """The reference's wrapper traces on an env that hands out bf16 / u8 observations (opt-in, ABI v4): the opponent
+    sees narrow observations, the agent gets narrow canonical observations, and every cell, mask bit, reward, flag
+    and side equals what the reference recorded."""
+    path = golden_files(golden_dir, "selfplay_")[idx]
+    log = np.load(path)
+    m, n, k, nenv, _ = (int(v) for v in log["geom"])
+    wrap = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV, obs_dtype=obs_dtype))
+    seen = []
+
+    class Spy:
+        def __init__(self, inner):
+            self.inner = inner
+
+        def act(self, obs):
+            seen.append(obs["observation"].dtype)
+            return self.inner.act(obs)
+
+    wrap.set_opponent(Spy(OPP[path.split("_")[-2]]()))
+    replay_selfplay_trace(wrap, log, lambda w, sides: w.force_sides(torch.from_numpy(sides.astype(np.int64))))
+    assert seen and all(d == obs_dtype for d in seen)
+
+
 # ----------------------------------------------------------------------------- the reference's own tests
 @pytest.fixture
 def wrapper_factory(hip):

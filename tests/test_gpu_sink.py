@@ -241,6 +241,30 @@ def test_ppo_learn_rollout_through_the_sink_equals_the_reference(hip, golden_dir
     assert second == small + row, (second, small + row)        # the carried-over observation: one row per learn call
 
 
+@pytest.mark.parametrize("obs_dtype", NARROW)
+def test_ppo_learn_rollout_through_a_narrow_sink_equals_the_reference(hip, golden_dir, obs_dtype):
+    """The same replay of the reference's learn rollouts with bf16 / u8 observations end to end: the env writes them
+    narrow, straight into a RolloutBuffer allocated in that dtype; every cell of every stored observation (and every
+    other field) still equals the reference buffer's."""
+    log = np.load(golden_files(golden_dir, "ppo_learn_")[1])
+    m, n, k, nenv, n_steps = (int(v) for v in log["geom"])
+    wrap = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV, obs_dtype=obs_dtype))
+    wrap.set_opponent(MaskHashPolicy(0 if m == 3 else 1))
+    wrap.track_episodes()
+    buf = hip.Buffer(n_steps, nenv, (2, m, n), m * n, device=DEV, obs_dtype=obs_dtype)
+    assert buf.observations.dtype == obs_dtype
+    wrap.attach_sink(buf)
+
+    def make_buffer(*_):
+        if buf.ptr:
+            buf.reset()
+        return buf
+
+    replay_ppo_learn(wrap, make_buffer, log, _set_sides, episode_stats=wrap.pop_episode_stats)
+    es = torch.empty((), dtype=obs_dtype).element_size()
+    assert buf.copied_bytes == 2 * n_steps * nenv * 17 + nenv * (2 * m * n * es + m * n)  # small vectors + one spill row
+
+
 def test_sink_rows_are_what_the_step_returns(hip):
     """With a sink attached the tensors a step returns ARE rows of the buffer; past the last row the step goes back
     to fresh tensors; a packed buffer takes the packed planes."""
