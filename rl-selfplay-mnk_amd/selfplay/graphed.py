@@ -126,6 +126,10 @@ class GraphedRollout:
     ``buffer``: ``alg.rollout_buffer.RolloutBuffer`` (dense rows) -- a ``PackedRolloutBuffer`` works with ``net=None``
     or a net that is fed from ``obs_scratch`` (the dense observation then ping-pongs between two scratch slots).
     Same kernels and random streams as the eager loop with ``FusedNNPolicy`` / ``RandomPolicy`` (seeded alike).
+
+    The wrapper (and its opponent's sampler) belong to the graph from here on: their Philox step counters live in the
+    graph's device counter, so eager ``wrapper.step`` calls in between would repeat random numbers -- use ``run()`` only,
+    or build a fresh wrapper for eager work.  ``recapture()`` after ``set_opponent`` or a weight swap by assignment.
     """
 
     def __init__(self, wrapper, buffer, net=None, seed=None):
