@@ -640,8 +640,7 @@ def main():
     import mnk_hip
     from env.torch_vector_mnk_env import TorchVectorMnkEnv
     from selfplay.exchange import RecordExchange
-    from selfplay.random_rollout import (ACT_BITS7, GatheredLogs, RandomRollout, action_log_format, gather_action_logs,
-                                         gather_start_state)
+    from selfplay.random_rollout import GatheredLogs, RandomRollout, gather_action_logs, gather_start_state
 
     mnk_hip.load()
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())

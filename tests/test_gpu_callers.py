@@ -2,8 +2,6 @@
 reference (tests/golden/make_golden_callers.py): SURVEY.md section 8 rows a18 (PPOAgent.learn rollout), a19/f1
 (RolloutBuffer + GAE -> mnk_gae), a20 (validate_gpu), f3 (tournament loop), f4 (minibatch gather from packed
 observations -> mnk_gather_obs).  Everything goes through the C ABI of libmnk_hip.so; bit-exact."""
-import os
-
 import numpy as np
 import pytest
 import torch

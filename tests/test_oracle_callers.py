@@ -5,7 +5,6 @@ import os
 
 import numpy as np
 import pytest
-import torch
 
 from oracle.callers import OracleRolloutBuffer, oracle_play_batch_games, oracle_validate
 from oracle.env_torch import OracleVectorEnv

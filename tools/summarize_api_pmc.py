@@ -4,7 +4,7 @@ tools/exp_kernels.py), next to their algorithmic bytes.
 usage: python tools/summarize_api_pmc.py <fetch dir> <write dir>  > profiles/r02_api_kernels_pmc.md
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reads half of a wide coalesced stream
 (/opt/skills/guides/MI355X_MICROARCH.md, HBM section): doubled here, as in tools/summarize_prof.py."""
-import collections, csv, glob, os, re, sys
+import collections, csv, glob, os, sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from summarize_api_kernels import BYTES, N9, S9, W9, C9, b_step, short  # noqa: E402
