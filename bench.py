@@ -778,6 +778,9 @@ def main():
 
     def barrier():
         if world > 1:
+            # drain this rank's streams first: the side stream's all-gathers run on the C ABI's communicator, the
+            # barrier on torch.distributed's -- two RCCL communicators are never in flight at the same time
+            torch.cuda.synchronize(dev)
             dist.barrier()
         torch.cuda.synchronize(dev)
 
