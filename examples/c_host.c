@@ -1,0 +1,167 @@
+/* c_host.c -- the C ABI of libmnk_hip.so driven from plain C99: no Python, no torch, no C++.
+ *
+ * What a non-Python host of the reference's rollout path (its env / RandomPolicy loop,
+ * src/selfplay/policy.py:18-29 -> src/env/torch_vector_mnk_env.py:55-84 -> :34-44) would write against
+ * include/mnk_hip.h: device memory from the HIP runtime, one stream, and
+ *   (A) mnk_rollout_random      T plies per env in one launch, packed records + statistics;
+ *   (B) mnk_step_random         the same T plies as T launches (BASELINE config 2 in one launch per ply),
+ *                               rewards / dones / legal mask per ply;
+ * and a check that (A) and (B) leave the same state and count the same finished games.
+ * Prints one line of key=value pairs; tests/test_gpu_c_host.py compares it with the Python binding's results.
+ *
+ *   gcc -std=c99 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/c_host.c -o examples/c_host \
+ *       -Lrl-selfplay-mnk_amd/mnk_hip -lmnk_hip -L/opt/rocm/lib -lamdhip64            (see __graft_entry__.build_c_host)
+ *   examples/c_host 9 9 5 4096 64 7        m n k envs plies seed
+ *   examples/c_host --abi                  version and sizes only: touches no GPU
+ */
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "mnk_hip.h"
+
+#define HIP_OK(call)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      fprintf(stderr, "c_host: %s failed: %s\n", #call, hipGetErrorString(e_));                   \
+      return 2;                                                                                   \
+    }                                                                                             \
+  } while (0)
+
+#define MNK_OK_(call)                                                                             \
+  do {                                                                                            \
+    int s_ = (call);                                                                              \
+    if (s_ != MNK_OK) {                                                                           \
+      fprintf(stderr, "c_host: %s returned %d (%s)\n", #call, s_, mnk_last_launch_error());       \
+      return 3;                                                                                   \
+    }                                                                                             \
+  } while (0)
+
+/* position-weighted sum modulo 2^64: sum of word[i] * (2i + 1) */
+static uint64_t checksum64(const uint64_t* w, size_t n) {
+  uint64_t s = 0;
+  for (size_t i = 0; i < n; ++i) s += w[i] * (2 * (uint64_t)i + 1);
+  return s;
+}
+
+static uint64_t checksum32(const uint32_t* w, size_t n) {
+  uint64_t s = 0;
+  for (size_t i = 0; i < n; ++i) s += (uint64_t)w[i] * (2 * (uint64_t)i + 1);
+  return s;
+}
+
+int main(int argc, char** argv) {
+  if (argc == 2 && strcmp(argv[1], "--abi") == 0) {
+    printf("abi=%d header_abi=%d words_9x9=%d record_words_9x9=%d words_19x19=%d supported_9x9x5=%d supported_2x2x3=%d\n",
+           mnk_abi_version(), MNK_ABI_VERSION, mnk_state_words(9, 9), mnk_record_words(9, 9), mnk_state_words(19, 19),
+           mnk_geometry_supported(9, 9, 5), mnk_geometry_supported(2, 2, 3));
+    return mnk_abi_version() == MNK_ABI_VERSION ? 0 : 1;
+  }
+  if (argc != 7) {
+    fprintf(stderr, "usage: %s m n k envs plies seed | --abi\n", argv[0]);
+    return 1;
+  }
+  const int m = atoi(argv[1]), n = atoi(argv[2]), k = atoi(argv[3]);
+  const int64_t N = atoll(argv[4]);
+  const int T = atoi(argv[5]);
+  const uint64_t seed = strtoull(argv[6], NULL, 10);
+  if (mnk_abi_version() != MNK_ABI_VERSION || !mnk_geometry_supported(m, n, k) || N < 1 || T < 1) {
+    fprintf(stderr, "c_host: unsupported arguments\n");
+    return 1;
+  }
+  const int W = mnk_state_words(m, n), R = mnk_record_words(m, n), C = m * n;
+  const size_t plane_words = (size_t)2 * W * N, rec_words = (size_t)T * R * N, rec_metas = (size_t)T * N;
+  const size_t stats_words = (size_t)MNK_STATS_REPLICAS * MNK_STATS_STRIDE;
+
+  hipStream_t stream;
+  HIP_OK(hipSetDevice(0));
+  HIP_OK(hipStreamCreate(&stream));
+  uint64_t *planes, *rec_planes, *planes_b;
+  uint32_t *meta, *rec_meta, *meta_b;
+  int64_t* stats;
+  float* rewards;
+  uint8_t *dones, *mask;
+  HIP_OK(hipMalloc((void**)&planes, plane_words * 8));
+  HIP_OK(hipMalloc((void**)&meta, (size_t)N * 4));
+  HIP_OK(hipMalloc((void**)&planes_b, plane_words * 8));
+  HIP_OK(hipMalloc((void**)&meta_b, (size_t)N * 4));
+  HIP_OK(hipMalloc((void**)&rec_planes, rec_words * 8));
+  HIP_OK(hipMalloc((void**)&rec_meta, rec_metas * 4));
+  HIP_OK(hipMalloc((void**)&stats, stats_words * 8));
+  HIP_OK(hipMalloc((void**)&rewards, (size_t)N * 4));
+  HIP_OK(hipMalloc((void**)&dones, (size_t)N));
+  HIP_OK(hipMalloc((void**)&mask, (size_t)N * C));
+  HIP_OK(hipMemsetAsync(stats, 0, stats_words * 8, stream));
+
+  /* (A) one launch: T plies per env, records and statistics */
+  MNK_OK_(mnk_reset_all(planes, meta, N, W, stream));
+  MNK_OK_(mnk_rollout_random(planes, meta, N, m, n, k, T, seed, /*step0=*/0, /*env_id0=*/0, rec_planes, rec_meta, stats,
+                             /*act_log=*/NULL, /*act_bytes=*/0, stream));
+
+  /* (B) T launches: draw + step + win scan + reset + legal mask of the next position, per ply */
+  MNK_OK_(mnk_reset_all(planes_b, meta_b, N, W, stream));
+  uint8_t* h_dones = (uint8_t*)malloc((size_t)N);
+  float* h_rewards = (float*)malloc((size_t)N * 4);
+  uint8_t* h_mask = (uint8_t*)malloc((size_t)N * C);
+  long long finished_b = 0, wins_b = 0, legal_last = 0;
+  for (int t = 0; t < T; ++t) {
+    MNK_OK_(mnk_step_random(planes_b, meta_b, N, m, n, k, seed, (uint64_t)t, /*step_dev=*/NULL, /*env_id0=*/0, MNK_STREAM_MOVE,
+                            /*actions_out=*/NULL, rewards, dones, mask, /*obs=*/NULL, MNK_OBS_F32, MNK_STEP_AUTORESET, stream));
+    HIP_OK(hipMemcpyAsync(h_dones, dones, (size_t)N, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipMemcpyAsync(h_rewards, rewards, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    for (int64_t i = 0; i < N; ++i) {
+      finished_b += h_dones[i] != 0;
+      wins_b += h_rewards[i] == 1.0f;
+    }
+  }
+  HIP_OK(hipMemcpyAsync(h_mask, mask, (size_t)N * C, hipMemcpyDeviceToHost, stream));
+
+  uint64_t* h_planes = (uint64_t*)malloc(plane_words * 8);
+  uint64_t* h_planes_b = (uint64_t*)malloc(plane_words * 8);
+  uint32_t* h_meta = (uint32_t*)malloc((size_t)N * 4);
+  uint32_t* h_meta_b = (uint32_t*)malloc((size_t)N * 4);
+  uint64_t* h_rec = (uint64_t*)malloc(rec_words * 8);
+  uint32_t* h_rec_meta = (uint32_t*)malloc(rec_metas * 4);
+  int64_t* h_stats = (int64_t*)malloc(stats_words * 8);
+  HIP_OK(hipMemcpyAsync(h_planes, planes, plane_words * 8, hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipMemcpyAsync(h_planes_b, planes_b, plane_words * 8, hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipMemcpyAsync(h_meta, meta, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipMemcpyAsync(h_meta_b, meta_b, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipMemcpyAsync(h_rec, rec_planes, rec_words * 8, hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipMemcpyAsync(h_rec_meta, rec_meta, rec_metas * 4, hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipMemcpyAsync(h_stats, stats, stats_words * 8, hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipStreamSynchronize(stream));
+
+  long long counters[MNK_STATS_COUNTERS] = {0};
+  for (int r = 0; r < MNK_STATS_REPLICAS; ++r)
+    for (int c = 0; c < MNK_STATS_COUNTERS; ++c) counters[c] += (long long)h_stats[r * MNK_STATS_STRIDE + c];
+  long long dones_in_records = 0;
+  for (size_t i = 0; i < rec_metas; ++i) dones_in_records += (h_rec_meta[i] >> MNK_REC_DONE_BIT) & 1u;
+  for (size_t i = 0; i < (size_t)N * C; ++i) legal_last += h_mask[i] != 0;
+  const int same_state = memcmp(h_planes, h_planes_b, plane_words * 8) == 0 && memcmp(h_meta, h_meta_b, (size_t)N * 4) == 0;
+
+  printf("abi=%d m=%d n=%d k=%d envs=%lld plies=%d seed=%llu episodes=%lld black_wins=%lld white_wins=%lld draws=%lld "
+         "length_sum=%lld dones_in_records=%lld planes_sum=%llu meta_sum=%llu rec_planes_sum=%llu rec_meta_sum=%llu "
+         "per_ply_finished=%lld per_ply_wins=%lld per_ply_legal_last=%lld per_ply_state_equals_rollout=%d\n",
+         mnk_abi_version(), m, n, k, (long long)N, T, (unsigned long long)seed, counters[0], counters[1], counters[2],
+         counters[3], counters[4], dones_in_records, (unsigned long long)checksum64(h_planes, plane_words),
+         (unsigned long long)checksum32(h_meta, (size_t)N), (unsigned long long)checksum64(h_rec, rec_words),
+         (unsigned long long)checksum32(h_rec_meta, rec_metas), finished_b, wins_b, legal_last, same_state);
+
+  const int ok = same_state && finished_b == counters[0] && dones_in_records == counters[0] &&
+                 wins_b == counters[1] + counters[2] && counters[1] + counters[2] + counters[3] == counters[0];
+  hipFree(planes); hipFree(meta); hipFree(planes_b); hipFree(meta_b); hipFree(rec_planes); hipFree(rec_meta);
+  hipFree(stats); hipFree(rewards); hipFree(dones); hipFree(mask);
+  hipStreamDestroy(stream);
+  free(h_dones); free(h_rewards); free(h_mask); free(h_planes); free(h_planes_b); free(h_meta); free(h_meta_b);
+  free(h_rec); free(h_rec_meta); free(h_stats);
+  if (!ok) {
+    fprintf(stderr, "c_host: the per-ply launches and the fused rollout disagree\n");
+    return 4;
+  }
+  return 0;
+}

@@ -100,3 +100,20 @@ def test_header_is_plain_c(tmp_path):
     inc = os.path.join(ROOT, "include")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)], check=True)
     subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)], check=True)
+
+
+def test_a_plain_c_host_links_against_the_library():
+    """examples/c_host.c (C99 + the HIP runtime's C API, no Python / torch / C++) builds against include/mnk_hip.h and
+    libmnk_hip.so; its ``--abi`` mode calls only the entry points that touch no GPU.  The GPU suite runs the rest
+    (tests/test_gpu_c_host.py)."""
+    import subprocess
+
+    import __graft_entry__ as entry
+
+    entry.build_hip()
+    exe = entry.build_c_host()
+    res = subprocess.run([exe, "--abi"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    got = dict(kv.split("=") for kv in res.stdout.split())
+    assert got == {"abi": "4", "header_abi": "4", "words_9x9": "2", "record_words_9x9": "3", "words_19x19": "6",
+                   "supported_9x9x5": "1", "supported_2x2x3": "0"}
