@@ -2,6 +2,8 @@
 batch sizes and operation sequences (full and subset steps with legal, occupied, negative and mixed actions; resets by
 index list, by bool mask and of everything; pokes through the dense views; wrapper steps with forced sides), every
 output and the whole state compared after every operation, bit for bit.  Fixed seeds: a failure reproduces."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -38,6 +40,15 @@ def hip():
     return ns
 
 
+def _seeds(default):
+    """the suite's seeds, or ``MNK_FUZZ_SEEDS=lo:hi`` for a one-off longer soak on other seeds"""
+    spec = os.environ.get("MNK_FUZZ_SEEDS")
+    if spec:
+        lo, hi = (int(v) for v in spec.split(":"))
+        return range(lo, hi)
+    return range(default)
+
+
 def _shape(rng):
     while True:
         m, n = int(rng.integers(2, 20)), int(rng.integers(2, 20))
@@ -56,7 +67,7 @@ def _same_obs(a, b, where):
     assert torch.equal(a["action_mask"].cpu(), b["action_mask"]), f"{where}: action_mask"
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", _seeds(10))
 def test_env_fuzz(hip, seed):
     rng = np.random.default_rng(7000 + seed)
     m, n, k = _shape(rng)
@@ -141,7 +152,7 @@ class _ForcedSides(OracleSelfPlay):
         return super().step(actions)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", _seeds(8))
 def test_wrapper_fuzz(hip, seed):
     rng = np.random.default_rng(9000 + seed)
     m, n, k = _shape(rng)
@@ -198,14 +209,13 @@ def test_wrapper_fuzz(hip, seed):
     wrap.env.check_errors()
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", _seeds(10))
 def test_rollout_and_log_fuzz(hip, seed):
     """Random boards, batch sizes and chunkings of the fused rollout with a random action-log format (byte, 16-bit, 7-bit
     stream where the board allows), message kind (with / without the chunk-start state) and kernel choice (generic or
     run-time specialised): records, statistics and final state == the oracle's raw loop; the log == the oracle's packing
     of the recorded actions; a replay of every chunk -- from the message's own state or from the receiver's running
     state -- rebuilds the records; one-launch plies (mnk_step_random) continue the same game stream ply for ply."""
-    import os
 
     rng = np.random.default_rng(11000 + seed)
     m, n, k = _shape(rng)
