@@ -121,7 +121,16 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device):
+    """hipStream_t of torch's current stream on ``device`` -- through the raw accessor where this torch has it (one C
+    call, ~0.3 us) instead of building a ``torch.cuda.Stream`` object per launch (~4 us of the ~18 us a step costs on
+    the host)"""
+    if _raw_stream is not None:
+        idx = device.index if isinstance(device, torch.device) else torch.device(device).index
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
     return torch.cuda.current_stream(device).cuda_stream
 
 
