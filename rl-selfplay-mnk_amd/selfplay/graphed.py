@@ -119,7 +119,9 @@ class GraphedRollout:
         roll = GraphedRollout(wrapper, buffer, net)       # wrapper.reset() is done inside
         for _ in range(iterations):
             roll.run()                                    # buffer.ptr == n_steps afterwards
-            buffer.compute_advantages_and_returns(roll.last_values(), gamma, lam); ...update...; buffer.reset()
+            nxt = roll.next_obs()                         # the observation after the last step (PPOAgent._last_obs)
+            _, last_values = net(nxt["observation"], nxt["action_mask"])
+            buffer.compute_advantages_and_returns(last_values, gamma, lam); ...update...; buffer.reset()
 
     ``net(obs, None) -> (dist, values)`` as every reference architecture; ``net=None`` is the uniformly random agent
     (``RandomPolicy``: the draw reads only the mask, values / log-probabilities of the uniform policy are written).
