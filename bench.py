@@ -22,6 +22,7 @@ state once before the first chunk (receivers must then replay every chunk to kee
 Rank 0 prints ONE JSON line (driver contract) with `roofline` and `cpu_baseline` objects.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -80,6 +81,15 @@ def parse():
                     help="--gather actions: every K-th chunk's message also carries the chunk-start state (a keyframe), so "
                          "any chunk's records can be rebuilt on demand from at most K messages; 1 = every message is "
                          "self-contained, 0 = the state is gathered once before the first chunk and never again")
+    ap.add_argument("--allgather", choices=("rccl", "direct"), default="rccl",
+                    help="form of the exchange step through the C ABI: rccl = ncclAllGather (RCCL picks the algorithm), "
+                         "direct = one grouped ncclSend + ncclRecv per peer (mnk_allgather_records_direct): every message "
+                         "once over each of the rank's own xGMI links.  Whichever runs in the timed loop, the line also "
+                         "times both forms alone (exchange.alone)")
+    ap.add_argument("--rehearse-exchange", action="store_true",
+                    help="on ONE GPU: run the multi-GPU code path anyway -- a process group of one rank, the C-ABI "
+                         "communicator, the exchange step on the side stream, both exchange forms alone -- so that every "
+                         "line of it has run on hardware before the driver's multi-GPU run (its numbers mean nothing)")
     ap.add_argument("--allow-fallback", action="store_true",
                     help="if the C-ABI RCCL communicator (mnk_comm_*) cannot be created, run the same all-gather through "
                          "torch.distributed instead of exiting non-zero")
@@ -604,6 +614,26 @@ def selfplay_config3(args, steps, warm):
     return out
 
 
+@contextlib.contextmanager
+def c_stdout_to_stderr():
+    """RCCL prints a version banner on the process's stdout when its first communicator comes up; stdout is for the ONE
+    JSON line.  File descriptor 1 points at stderr while communicators are created (C-level writes included)."""
+    import ctypes
+
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def spawn_ranks(n):
     """``python bench.py --gpus N`` without a launcher: start N fresh rank processes (one per GPU, the env
     variables torch.distributed.run would set), relay their output -- rank 0 prints the JSON line -- and exit
@@ -646,20 +676,31 @@ def main():
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.rehearse_exchange  # the code path with a process group and an exchange step
+    if multi:
         import torch.distributed as dist
 
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        if world == 1:  # rehearsal: no launcher set these
+            import socket
+
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+
+        with c_stdout_to_stderr():
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.barrier()  # brings the backend's communicator up now (a lazily initialising backend would do it later)
 
     m, n, k = (int(v) for v in args.board.split("x"))
     nenv, chunk = args.envs, args.chunk
     env = TorchVectorMnkEnv(m, n, k, nenv, device=str(dev))
     env.reset()
     roll = RandomRollout(env, seed=args.seed, env_id0=rank * nenv)
-    mode = args.gather if world > 1 else "none"
+    mode = args.gather if multi else "none"
     logging = mode == "actions"
     if logging:  # a group of the log holds plies 4q..4q+3: chunks (and so the warm-up) end on multiples of 4
         chunk = args.chunk = max(4, chunk - chunk % 4)
@@ -688,7 +729,8 @@ def main():
         if args.backend == "nccl":  # the collective goes through the C ABI (mnk_allgather_records), RCCL over xGMI
             failure = None
             try:
-                exchange = RecordExchange.from_process_group()
+                with c_stdout_to_stderr():
+                    exchange = RecordExchange.from_process_group()
             except Exception as e:  # noqa: BLE001
                 failure = e
                 exchange = None
@@ -716,6 +758,8 @@ def main():
             if bufs_log is not None:
                 gathered_log = [GatheredLogs.empty(world, 0, nenv, chunk, env.max_moves, dev, fmt=bufs[0].fmt,
                                                    with_state=False) for _ in bufs]
+    if exchange is not None:
+        exchange.direct = args.allgather == "direct"
     main_stream = torch.cuda.current_stream(dev)
     gather_done = [None, None]
     kernel_events = []  # (start, end) HIP events around every rollout launch of the timed region
@@ -776,8 +820,35 @@ def main():
             main_stream.wait_stream(side)
         return launches
 
+    def exchange_alone_ms(reps=8, limit_s=60.0):
+        """`reps` exchange steps of the every-chunk message back to back on the side stream with nothing else running,
+        by HIP events (this rank's mean); None if they do not finish within `limit_s` -- the caller then prints its
+        line and leaves without touching a collective again (a first run of an exchange form on a new node must not be
+        able to hang the job)."""
+        src = (bufs_log or bufs)[0]
+        events = []
+        barrier()
+        with torch.cuda.stream(side):
+            for _ in range(reps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(side)
+                if logging:
+                    gather_action_logs(src, out=(gathered_log or gathered)[0], exchange=exchange, stream=side)
+                else:
+                    gp, gm = gathered[0]
+                    exchange.all_gather(src.planes.view(-1), gp.view(-1), side)
+                    exchange.all_gather(src.meta.view(-1), gm.view(-1), side)
+                b.record(side)
+                events.append((a, b))
+        t_start = time.perf_counter()
+        while not events[-1][1].query():
+            if time.perf_counter() - t_start > limit_s:
+                return None
+            time.sleep(0.001)
+        return sum(a.elapsed_time(b) for a, b in events) / reps
+
     def barrier():
-        if world > 1:
+        if multi:
             # drain this rank's streams first: the side stream's all-gathers run on the C ABI's communicator, the
             # barrier on torch.distributed's -- two RCCL communicators are never in flight at the same time
             torch.cuda.synchronize(dev)
@@ -804,7 +875,7 @@ def main():
     dt = time.perf_counter() - t0
     # time spent in the rollout kernel (HIP events on the stream it is launched on)
     dev_ms = sum(a.elapsed_time(b) for a, b in kernel_events) if kernel_events else region0.elapsed_time(region1)
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -821,7 +892,7 @@ def main():
         run_steps(args.steps * chunk)
         barrier()
         rdt = time.perf_counter() - r0
-        if world > 1:
+        if multi:
             rmax = torch.tensor([rdt], dtype=torch.float64, device=dev)
             dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
             rdt = float(rmax.item())
@@ -924,7 +995,8 @@ def main():
                      "records": "packed records (rows + meta word per ply)"}[mode],
             "keyframe_every_chunks": keyframe if logging else None,
             "start_state_bytes_per_rank": start_state.msg.shape[1] * 8 if start_state is not None else 0,
-            "transport": "mnk_allgather_records (C ABI, RCCL)" if exchange is not None
+            "transport": ("mnk_allgather_records_direct" if exchange.direct else "mnk_allgather_records") + " (C ABI, RCCL)"
+                         if exchange is not None
                          else f"torch.distributed {args.backend}" + (" (FALLBACK: the C-ABI communicator failed)"
                                                                      if args.backend == "nccl" else ""),
             "bytes_per_rank_per_chunk": msg_bytes,
@@ -939,14 +1011,37 @@ def main():
             "exposed_ms_per_chunk": exposed_ms,           # step time minus the compute-only step time
             "overlap_fraction": max(0.0, 1.0 - exposed_ms / mean_ms) if mean_ms else None,
         }
+    if args.rehearse_exchange and world == 1:
+        out["rehearsal"] = "the multi-GPU code path on one GPU (a one-rank communicator): not a measurement"
     if mode != "none":
         out["transport"] = out["exchange"]["transport"]
+        out["exchange"]["algorithm"] = ("one grouped ncclSend + ncclRecv per peer (mnk_allgather_records_direct)"
+                                        if exchange is not None and exchange.direct else
+                                        "ncclAllGather" if exchange is not None else "all_gather_into_tensor")
+    # both forms of the exchange step alone (rank 0's clock): the one of the timed loop first, the other one last and
+    # under a watchdog, because the driver's multi-GPU run is the first time it meets more than one GPU
+    alone = None
+    exchange_hung = False
+    if exchange is not None:
+        alone = {}
+        for form in ((False, True) if not exchange.direct else (True, False)):
+            exchange.direct = form
+            ms = exchange_alone_ms()
+            alone["direct_sendrecv_ms" if form else "ncclAllGather_ms"] = ms
+            if ms is None:
+                exchange_hung = True
+                break
+        exchange.direct = args.allgather == "direct"
+    if alone is not None:
+        alone["what"] = ("the exchange step of the every-chunk message alone (8 back to back, nothing else running, this "
+                         "rank's HIP events); null = did not finish within 60 s")
+        out["exchange"]["alone"] = alone
     if rank == 0:
         stats = roll.stats.tolist()
         out["rollout_stats"] = {"episodes": stats[0], "mean_plies": stats[4] / max(stats[0], 1),
                                 "draw_rate": stats[3] / max(stats[0], 1)}
         out["gpu"] = gpu_identity(dev)
-        if world == 1 and not args.no_api_path:
+        if not multi and not args.no_api_path:
             out["roofline"]["measured_write_ceiling_GBps"] = write_ceiling_GBps(dev, nenv, chunk, rows)
             out["roofline"]["frac_of_measured_write_ceiling"] = achieved / out["roofline"]["measured_write_ceiling_GBps"]
             out["api_path_env_steps_per_s"] = api_path_rate(env, args.seed)
@@ -973,15 +1068,18 @@ def main():
                                                                    "env_side_ms_per_step", "nn_and_sampling_ms_per_step",
                                                                    "buffer_add_copied_bytes_per_agent_step")}
             out["selfplay"]["config3"]["workload"] = c3["config"]["workload"]
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(env, args.cpu_seconds, args.cpu_threads)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+    if exchange_hung:  # an exchange form never finished: no synchronisation or collective can be trusted any more
+        sys.stdout.flush()
+        os._exit(0)
     if exchange is not None:
         torch.cuda.synchronize(dev)
         exchange.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -318,6 +318,10 @@ int mnk_comm_unique_id(void* id_out_host);
 int mnk_comm_init(void** comm_out, const void* id_host, int nranks, int rank);
 int mnk_comm_destroy(void* comm);
 int mnk_allgather_records(void* comm, const void* send, void* recv, int64_t bytes, void* stream);
+/* The same exchange as one send and one receive per peer (ncclSend / ncclRecv in one group, peers in rotated order):
+ * on the fully connected xGMI mesh every rank's message then travels once over each of its own links, where a ring
+ * all-gather forwards it hop by hop.  Same arguments and result layout; send and recv must not overlap. */
+int mnk_allgather_records_direct(void* comm, const void* send, void* recv, int64_t bytes, void* stream);
 const char* mnk_comm_last_error(void);
 /* NCCL_VERSION_CODE of the resolved library, 0 when none could be resolved */
 int mnk_comm_version(void);

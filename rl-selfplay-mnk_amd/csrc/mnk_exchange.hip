@@ -23,7 +23,15 @@ struct Rccl {
   decltype(&ncclAllGather) all_gather = nullptr;
   decltype(&ncclGetErrorString) error_string = nullptr;
   decltype(&ncclGetVersion) get_version = nullptr;
+  // the direct form of the exchange: one send and one receive per peer, grouped
+  decltype(&ncclGroupStart) group_start = nullptr;
+  decltype(&ncclGroupEnd) group_end = nullptr;
+  decltype(&ncclSend) send = nullptr;
+  decltype(&ncclRecv) recv = nullptr;
+  decltype(&ncclCommCount) comm_count = nullptr;
+  decltype(&ncclCommUserRank) comm_user_rank = nullptr;
   bool ok = false;
+  bool p2p_ok = false;
 };
 
 thread_local char g_comm_err[256] = "";
@@ -42,7 +50,14 @@ const Rccl& rccl() {
     t.all_gather = (decltype(t.all_gather))dlsym(h, "ncclAllGather");
     t.error_string = (decltype(t.error_string))dlsym(h, "ncclGetErrorString");
     t.get_version = (decltype(t.get_version))dlsym(h, "ncclGetVersion");
+    t.group_start = (decltype(t.group_start))dlsym(h, "ncclGroupStart");
+    t.group_end = (decltype(t.group_end))dlsym(h, "ncclGroupEnd");
+    t.send = (decltype(t.send))dlsym(h, "ncclSend");
+    t.recv = (decltype(t.recv))dlsym(h, "ncclRecv");
+    t.comm_count = (decltype(t.comm_count))dlsym(h, "ncclCommCount");
+    t.comm_user_rank = (decltype(t.comm_user_rank))dlsym(h, "ncclCommUserRank");
     t.ok = t.get_unique_id && t.comm_init_rank && t.comm_destroy && t.all_gather && t.error_string;
+    t.p2p_ok = t.ok && t.group_start && t.group_end && t.send && t.recv && t.comm_count && t.comm_user_rank;
     return t;
   }();
   return r;
@@ -107,6 +122,38 @@ int mnk_allgather_records(void* comm, const void* send, void* recv, int64_t byte
   return comm_status("ncclAllGather",
                      rccl().all_gather(send, recv, wide ? (size_t)(bytes / 8) : (size_t)bytes,
                                        wide ? ncclUint64 : ncclUint8, (ncclComm_t)comm, (hipStream_t)stream));
+}
+
+int mnk_allgather_records_direct(void* comm, const void* send, void* recv, int64_t bytes, void* stream) {
+  if (!comm || !send || !recv || bytes < 0) return MNK_EINVAL;
+  if (bytes == 0) return MNK_OK;
+  if (int rc = need_rccl()) return rc;
+  const Rccl& r = rccl();
+  if (!r.p2p_ok) {
+    snprintf(g_comm_err, sizeof(g_comm_err), "ncclSend / ncclRecv / ncclGroup* could not be resolved from librccl");
+    return MNK_ECOMM;
+  }
+  int nranks = 0, rank = 0;
+  if (int rc = comm_status("ncclCommCount", r.comm_count((ncclComm_t)comm, &nranks))) return rc;
+  if (int rc = comm_status("ncclCommUserRank", r.comm_user_rank((ncclComm_t)comm, &rank))) return rc;
+  const bool wide = (bytes % 8 == 0) && (((uintptr_t)send | (uintptr_t)recv) % 8 == 0);
+  const size_t count = wide ? (size_t)(bytes / 8) : (size_t)bytes;
+  const ncclDataType_t type = wide ? ncclUint64 : ncclUint8;
+  // every rank posts its sends and receives in the same rotated order (peer = rank + i): at step i of the rotation every
+  // link of the mesh carries exactly one message in each direction.  The rank's own slot goes through the same calls
+  // (RCCL turns a send to oneself into a local copy), so a one-rank communicator exercises the whole path.
+  if (int rc = comm_status("ncclGroupStart", r.group_start())) return rc;
+  ncclResult_t first = ncclSuccess;
+  for (int i = 0; i < nranks; ++i) {
+    const int to = (rank + i) % nranks, from = (rank - i + nranks) % nranks;
+    ncclResult_t a = r.send(send, count, type, to, (ncclComm_t)comm, (hipStream_t)stream);
+    ncclResult_t b = r.recv((char*)recv + (size_t)from * (size_t)bytes, count, type, from, (ncclComm_t)comm,
+                            (hipStream_t)stream);
+    if (first == ncclSuccess) first = a != ncclSuccess ? a : b;
+  }
+  ncclResult_t end = r.group_end();  // always closed, also after a failed post
+  if (first != ncclSuccess) return comm_status("ncclSend / ncclRecv", first);
+  return comm_status("ncclGroupEnd", end);
 }
 
 }  // extern "C"

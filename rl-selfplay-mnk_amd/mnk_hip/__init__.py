@@ -66,6 +66,7 @@ SIGNATURES = {
     "mnk_comm_init": [_vp, _vp, _i, _i],
     "mnk_comm_destroy": [_vp],
     "mnk_allgather_records": [_vp, _vp, _vp, _i64, _vp],
+    "mnk_allgather_records_direct": [_vp, _vp, _vp, _i64, _vp],
     "mnk_comm_last_error": [],
     "mnk_comm_version": [],
     "mnk_probe_record_writes": [_vp, _i64, _i, _i, _vp],

@@ -31,6 +31,9 @@ class RecordExchange:
         buf = ctypes.create_string_buffer(comm_id, mnk_hip.COMM_ID_BYTES)
         mnk_hip.call("mnk_comm_init", ctypes.byref(handle), buf, self.world, self.rank)
         self._comm = handle
+        # False: ncclAllGather (RCCL picks the algorithm); True: one grouped send + receive per peer, every message
+        # once over each of the rank's own xGMI links (mnk_allgather_records_direct)
+        self.direct = False
 
     @staticmethod
     def new_id() -> bytes:
@@ -48,16 +51,19 @@ class RecordExchange:
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         return cls(rank, world, box[0])
 
-    def all_gather(self, send: torch.Tensor, recv: torch.Tensor, stream: Optional[torch.cuda.Stream] = None) -> None:
+    def all_gather(self, send: torch.Tensor, recv: torch.Tensor, stream: Optional[torch.cuda.Stream] = None,
+                   direct: Optional[bool] = None) -> None:
         """recv[r] = rank r's ``send`` for every r; ``recv`` holds ``world * send.numel()`` elements of the same
-        dtype.  Enqueued on ``stream`` (default: the current stream of ``send``'s device); returns at once."""
+        dtype.  Enqueued on ``stream`` (default: the current stream of ``send``'s device); returns at once.
+        ``direct`` (default: ``self.direct``) picks the per-peer send / receive form of the exchange."""
         nbytes = send.numel() * send.element_size()
         if recv.numel() * recv.element_size() != self.world * nbytes:
             raise ValueError(f"recv holds {recv.numel() * recv.element_size()} bytes, need {self.world} x {nbytes}")
         if send.device != recv.device or send.device.type != "cuda":
             raise ValueError("send and recv must live on the same GPU")
         s = stream.cuda_stream if stream is not None else mnk_hip.stream_ptr(send.device)
-        mnk_hip.call("mnk_allgather_records", self._comm, mnk_hip.ptr(send), mnk_hip.ptr(recv), nbytes, s)
+        entry = "mnk_allgather_records_direct" if (self.direct if direct is None else direct) else "mnk_allgather_records"
+        mnk_hip.call(entry, self._comm, mnk_hip.ptr(send), mnk_hip.ptr(recv), nbytes, s)
 
     def close(self) -> None:
         if self._comm is not None and self._comm.value:

@@ -83,6 +83,22 @@ torch.cuda.current_stream().wait_stream(side)
 assert torch.equal(logs2.msg[0], rec.msg)
 again = replay_shard(logs2, 0, 9, 9, 5)
 assert torch.equal(again.planes, rec.planes) and torch.equal(again.meta, rec.meta)
+# the per-peer send / receive form of the exchange (mnk_allgather_records_direct): ncclGroupStart / ncclSend / ncclRecv /
+# ncclGroupEnd -- on one rank the message travels to "peer 0", i.e. through RCCL's send-to-self
+ex.direct = True
+roll.run(64, out=rec)
+done.record()
+with torch.cuda.stream(side):
+    side.wait_event(done)
+    logs3 = gather_action_logs(rec, exchange=ex, stream=side)
+torch.cuda.current_stream().wait_stream(side)
+assert torch.equal(logs3.msg[0], rec.msg)
+odd = torch.arange(1, 1 + 13, dtype=torch.uint8, device=dev)   # a message that is not a multiple of 8 bytes
+got = torch.zeros(13, dtype=torch.uint8, device=dev)
+ex.all_gather(odd, got)
+torch.cuda.synchronize()
+assert torch.equal(got, odd)
+ex.direct = False
 try:
     ex.all_gather(rec.msg, torch.empty(3, dtype=torch.int64, device=dev))
     raise SystemExit("a short receive buffer was accepted")
@@ -168,3 +184,28 @@ def test_two_ranks_exchange_keyframed_logs_and_rebuild_each_others_records(m, n,
     outs = [p.communicate(timeout=600) for p in procs]
     for rank, (out, err) in enumerate(outs):
         assert f"RANK_OK {rank}" in out, out[-2000:] + err[-4000:]
+
+
+@pytest.mark.parametrize("extra", [[], ["--allgather", "direct", "--keyframe", "1"], ["--gather", "records"]])
+def test_bench_multi_gpu_code_path_rehearsed_on_one_gpu(extra):
+    """``bench.py --rehearse-exchange``: the code path the driver's multi-GPU run takes -- process group (RCCL), the C ABI's
+    communicator, the exchange step on a side stream overlapping the next chunk, both exchange forms timed alone under a
+    watchdog -- with one rank on this box's GPU.  stdout must hold the ONE JSON line and nothing else (RCCL's version
+    banner goes to stderr)."""
+    import json
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for var in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(var, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-exchange", "--steps", "6", "--warmup", "2",
+                          "--settle", "8", "--envs", "8192"] + extra, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and "rehearsal" in d and d["gather"] == ("records" if "records" in extra else "actions")
+    ex = d["exchange"]
+    assert d["transport"] == ex["transport"] and "C ABI, RCCL" in ex["transport"]
+    assert ("direct" in ex["transport"]) == ("direct" in extra)
+    assert ex["alone"]["ncclAllGather_ms"] > 0 and ex["alone"]["direct_sendrecv_ms"] > 0
+    assert d["value"] > 0 and d["value_without_exchange"] > 0 and ex["allgather_ms"] > 0
