@@ -81,11 +81,13 @@ def parse():
                     help="--gather actions: every K-th chunk's message also carries the chunk-start state (a keyframe), so "
                          "any chunk's records can be rebuilt on demand from at most K messages; 1 = every message is "
                          "self-contained, 0 = the state is gathered once before the first chunk and never again")
-    ap.add_argument("--allgather", choices=("rccl", "direct"), default="rccl",
+    ap.add_argument("--allgather", choices=("auto", "rccl", "direct"), default="auto",
                     help="form of the exchange step through the C ABI: rccl = ncclAllGather (RCCL picks the algorithm), "
                          "direct = one grouped ncclSend + ncclRecv per peer (mnk_allgather_records_direct): every message "
                          "once over each of the rank's own xGMI links.  Whichever runs in the timed loop, the line also "
-                         "times both forms alone (exchange.alone)")
+                         "times both forms alone (exchange.alone).  auto (default): the timed loop runs with ncclAllGather; if "
+                         "the direct form alone is at least 10 %% faster on the slowest rank, warm-up and timed region are "
+                         "run again with it and the better of the two is `value` (the other one stays in the line)")
     ap.add_argument("--rehearse-exchange", action="store_true",
                     help="on ONE GPU: run the multi-GPU code path anyway -- a process group of one rank, the C-ABI "
                          "communicator, the exchange step on the side stream, both exchange forms alone -- so that every "
@@ -1032,6 +1034,50 @@ def main():
                 exchange_hung = True
                 break
         exchange.direct = args.allgather == "direct"
+    if alone is not None and not exchange_hung and args.allgather == "auto":
+        # every rank decides on the same numbers: the slowest rank's
+        both = torch.tensor([alone["ncclAllGather_ms"], alone["direct_sendrecv_ms"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(both, op=dist.ReduceOp.MAX)
+        alone["slowest_rank"] = {"ncclAllGather_ms": float(both[0].item()), "direct_sendrecv_ms": float(both[1].item())}
+        if float(both[1].item()) < 0.9 * float(both[0].item()) or os.environ.get("MNK_BENCH_FORCE_DIRECT") == "1":
+            exchange.direct = True
+            del kernel_events[:], gather_events[:]
+            run_steps(args.warmup * chunk)
+            barrier()
+            timing[0] = True
+            d0 = time.perf_counter()
+            assert run_steps(args.steps * chunk) == args.steps
+            barrier()
+            ddt = time.perf_counter() - d0
+            timing[0] = False
+            dmean = sum(a.elapsed_time(b) for a, b in gather_events) / max(len(gather_events), 1)
+            second = torch.tensor([ddt, dmean * 1e-3], dtype=torch.float64, device=dev)
+            dist.all_reduce(second, op=dist.ReduceOp.MAX)
+            ddt, dmean = float(second[0].item()), float(second[1].item()) * 1e3
+            dvalue = world * nenv * plies / ddt
+            ex = out["exchange"]
+            tried = {"value": dvalue, "ms_per_step": ddt * 1e3 / args.steps, "allgather_ms": dmean}
+            if dvalue > out["value"]:
+                ex["with_ncclAllGather"] = {"value": out["value"], "ms_per_step": out["ms_per_step"],
+                                            **{key: ex[key] for key in ("allgather_ms", "recv_GBps_per_rank", "per_link_GBps",
+                                                                        "exposed_ms_per_chunk", "overlap_fraction")}}
+                out["value"], out["ms_per_step"] = dvalue, tried["ms_per_step"]
+                exposed = max(0.0, tried["ms_per_step"] - ex["compute_ms_per_chunk"])
+                ex.update(allgather_ms=dmean, exposed_ms_per_chunk=exposed,
+                          recv_GBps_per_rank=(world - 1) * ex["bytes_per_rank_per_chunk"] / (dmean * 1e-3) / 1e9 if dmean else None,
+                          per_link_GBps=ex["bytes_per_rank_per_chunk"] / (dmean * 1e-3) / 1e9 if dmean else None,
+                          overlap_fraction=max(0.0, 1.0 - exposed / dmean) if dmean else None,
+                          algorithm="one grouped ncclSend + ncclRecv per peer (mnk_allgather_records_direct)",
+                          transport="mnk_allgather_records_direct (C ABI, RCCL)")
+                out["transport"] = ex["transport"]
+                out["repetitions"]["note"] = "the repetitions ran with ncclAllGather; `value` is the re-run with the direct form"
+                ex["auto"] = "switched to the direct form: faster alone and in the loop"
+            else:
+                ex["with_direct_sendrecv"] = tried
+                ex["auto"] = "kept ncclAllGather: the direct form was faster alone but not in the loop"
+                exchange.direct = False
+        else:
+            out["exchange"]["auto"] = "kept ncclAllGather: the direct form alone was not 10 % faster on the slowest rank"
     if alone is not None:
         alone["what"] = ("the exchange step of the every-chunk message alone (8 back to back, nothing else running, this "
                          "rank's HIP events); null = did not finish within 60 s")

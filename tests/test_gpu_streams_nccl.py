@@ -186,7 +186,7 @@ def test_two_ranks_exchange_keyframed_logs_and_rebuild_each_others_records(m, n,
         assert f"RANK_OK {rank}" in out, out[-2000:] + err[-4000:]
 
 
-@pytest.mark.parametrize("extra", [[], ["--allgather", "direct", "--keyframe", "1"], ["--gather", "records"]])
+@pytest.mark.parametrize("extra", [[], ["--allgather", "direct", "--keyframe", "1"], ["--gather", "records"], ["FORCE_SWITCH"]])
 def test_bench_multi_gpu_code_path_rehearsed_on_one_gpu(extra):
     """``bench.py --rehearse-exchange``: the code path the driver's multi-GPU run takes -- process group (RCCL), the C ABI's
     communicator, the exchange step on a side stream overlapping the next chunk, both exchange forms timed alone under a
@@ -197,6 +197,10 @@ def test_bench_multi_gpu_code_path_rehearsed_on_one_gpu(extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for var in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(var, None)
+    force = extra == ["FORCE_SWITCH"]
+    if force:  # --allgather auto's second timed region (taken when the direct form is faster alone), forced
+        env["MNK_BENCH_FORCE_DIRECT"] = "1"
+        extra = []
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-exchange", "--steps", "6", "--warmup", "2",
                           "--settle", "8", "--envs", "8192"] + extra, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -206,6 +210,12 @@ def test_bench_multi_gpu_code_path_rehearsed_on_one_gpu(extra):
     assert d["n_gpus"] == 1 and "rehearsal" in d and d["gather"] == ("records" if "records" in extra else "actions")
     ex = d["exchange"]
     assert d["transport"] == ex["transport"] and "C ABI, RCCL" in ex["transport"]
-    assert ("direct" in ex["transport"]) == ("direct" in extra)
+    if not force:
+        assert ("direct" in ex["transport"]) == ("direct" in extra)
     assert ex["alone"]["ncclAllGather_ms"] > 0 and ex["alone"]["direct_sendrecv_ms"] > 0
     assert d["value"] > 0 and d["value_without_exchange"] > 0 and ex["allgather_ms"] > 0
+    if "--allgather" not in extra:
+        assert ex["alone"]["slowest_rank"]["ncclAllGather_ms"] > 0 and "auto" in ex
+        if force:
+            assert ("with_ncclAllGather" in ex) != ("with_direct_sendrecv" in ex)
+            assert ("direct" in ex["transport"]) == ("with_ncclAllGather" in ex)
