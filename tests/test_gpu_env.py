@@ -578,7 +578,8 @@ def _fuzz_geometries(count, seed):
 
 
 @pytest.mark.parametrize("m,n,k", _fuzz_geometries(24, seed=2026) + [(22, 22, 10), (9, 9, 4), (9, 9, 9), (2, 22, 2),
-                                                                      (22, 2, 2), (15, 15, 5), (12, 9, 5)])
+                                                                      (22, 2, 2), (15, 15, 5), (12, 9, 5),
+                                                                      (1, 7, 1), (1, 61, 1), (5, 5, 1), (3, 61, 3)])  # one-row boards, k = 1, widest row
 def test_generic_geometries_match_oracle(hip, m, n, k):
     """Boards outside the ahead-of-time specialisations (and odd ones inside them), both ways they can run: the
     generic kernels with run-time shifts (MNK_JIT=0) -- including shift amounts >= 32 and k up to 10 -- and the
