@@ -48,3 +48,39 @@ for N in (384, 1024, 4096, 65536):
         t_graph = wall(g.step, 200)
         print(f"N={N:6d} opponent={opp_kind:6s}  eager {t_eager:8.1f} us/step ({N/t_eager*1e6:.3e} agent-steps/s)   "
               f"hipGraph {t_graph:8.1f} us/step ({N/t_graph*1e6:.3e})   x{t_eager/t_graph:.2f}", flush=True)
+
+# ---- the whole rollout (n_steps agent-steps) as ONE hipGraph writing the rollout buffer's rows (GraphedRollout) against
+# the reference-shaped eager loop (net -> sample -> wrapper.step -> buffer.add) with the sink attached
+from alg.rollout_buffer import RolloutBuffer
+from selfplay.graphed import GraphedRollout
+
+T = 64
+for N in (384, 1024, 4096):
+    for opp_kind in ("random", "nn"):
+        torch.manual_seed(0)
+        net, opp_net = ConvNet().to(DEV).eval(), ConvNet().to(DEV).eval()
+        def make():
+            w = TorchSelfPlayWrapper(TorchVectorMnkEnv(m, n, k, N, device=DEV), seed=1)
+            w.set_opponent(RandomPolicy(c, seed=2) if opp_kind == "random" else FusedNNPolicy(opp_net, seed=2))
+            return w
+        w = make(); buf = RolloutBuffer(T, N, (2, m, n), c, device=DEV); w.attach_sink(buf)
+        obs, _ = w.reset(); state = {"obs": obs}
+        def eager_rollout():
+            for _ in range(T):
+                o = state["obs"]
+                with torch.no_grad():
+                    dist, values = net(o["observation"], o["action_mask"])
+                    a = dist.sample(); lp = dist.log_prob(a)
+                nxt, r, term, trunc, _ = w.step(a)
+                buf.add(o["observation"], a, r, values, lp, term | trunc, o["action_mask"])
+                state["obs"] = nxt
+            buf.reset()
+        t_eager = wall(eager_rollout, 5) / T
+        buf2 = RolloutBuffer(T, N, (2, m, n), c, device=DEV)
+        g = GraphedRollout(make(), buf2, net, seed=3)
+        def graphed_rollout():
+            g.run(); buf2.reset()
+        t_graph = wall(graphed_rollout, 20) / T
+        print(f"rollout of {T} steps, N={N:5d} opponent={opp_kind:6s}  eager loop (torch Categorical, sink) {t_eager:8.1f} us/step "
+              f"({N/t_eager*1e6:.3e} agent-steps/s)   one hipGraph {t_graph:8.1f} us/step ({N/t_graph*1e6:.3e})   x{t_eager/t_graph:.2f}",
+              flush=True)
