@@ -89,3 +89,19 @@ def test_round3_rehearsal_lines_cover_every_exchange_mode():
     for x in lines:
         assert x["n_gpus"] == 2 and x["gather"] == x["config"]["gather"] and x["transport"] == x["exchange"]["transport"]
         assert ("7-bit" in x["kernel_variant"]) == (x["gather"] == "actions")
+
+
+def test_rehearsed_exchange_lines_time_both_forms():
+    """Round 3: the multi-GPU code path rehearsed with a one-rank RCCL communicator (`bench.py --rehearse-exchange`): the C
+    ABI's transport, the exchange algorithm in the line, both exchange forms timed alone."""
+    with open(os.path.join(ROOT, "profiles", "r03_bench_rehearse_exchange_lines.json")) as f:
+        lines = [json.loads(ln) for ln in f.read().splitlines() if ln.startswith("{")]
+    assert len(lines) == 4
+    for d in lines:
+        assert d["n_gpus"] == 1 and "rehearsal" in d and d["cpu_baseline"] is None
+        x = d["exchange"]
+        assert "C ABI, RCCL" in x["transport"] and d["transport"] == x["transport"]
+        assert ("direct" in x["transport"]) == x["algorithm"].startswith("one grouped ncclSend")
+        assert x["alone"]["ncclAllGather_ms"] > 0 and x["alone"]["direct_sendrecv_ms"] > 0
+    assert sorted(d["gather"] for d in lines) == ["actions", "actions", "actions", "records"]
+    assert {round(d["exchange"]["bytes_per_env_step"], 3) for d in lines} == {0.893, 1.016, 28.0}
