@@ -92,10 +92,83 @@ def parse():
                     help="on ONE GPU: run the multi-GPU code path anyway -- a process group of one rank, the C-ABI "
                          "communicator, the exchange step on the side stream, both exchange forms alone -- so that every "
                          "line of it has run on hardware before the driver's multi-GPU run (its numbers mean nothing)")
+    ap.add_argument("--exchange-every", type=int, default=1, metavar="J",
+                    help="--gpus > 1: ONE all-gather per J chunks carrying the J chunks' messages end to end (J times the "
+                         "bytes per call): amortises RCCL's per-call cost and moves the message up the xGMI size curve; "
+                         "two runs with different J give the inbound rate at two message sizes.  --steps, --warmup and "
+                         "--settle must be multiples of J")
+    ap.add_argument("--alone-limit", type=float, default=60.0,
+                    help="seconds an exchange form timed alone (exchange.alone) may take before it is declared hung: the line "
+                         "is printed with `exchange_hung` and every rank leaves with exit code 4")
+    ap.add_argument("--phase-timeout", type=float, default=300.0,
+                    help="multi-rank runs: a phase of the bench (set-up, warm-up, timed region, ...) that takes longer than "
+                         "this many seconds is taken to be a hung collective: the rank says which phase on stderr and "
+                         "leaves with exit code 5 instead of sitting there until the driver's limit (0 = off)")
     ap.add_argument("--allow-fallback", action="store_true",
                     help="if the C-ABI RCCL communicator (mnk_comm_*) cannot be created, run the same all-gather through "
                          "torch.distributed instead of exiting non-zero")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.exchange_every < 1:
+        ap.error("--exchange-every must be at least 1")
+    if args.exchange_every > 1 and any(v % args.exchange_every for v in (args.steps, args.warmup, args.settle)):
+        ap.error("--steps, --warmup and --settle must be multiples of --exchange-every")
+    return args
+
+
+EXIT_COMM, EXIT_HUNG, EXIT_PHASE = 3, 4, 5  # no C-ABI communicator on every rank / an exchange form never finished / a phase timed out
+
+
+class PhaseWatchdog:
+    """A thread that ends the process (exit code EXIT_PHASE, the phase named on stderr) when one phase of a multi-rank
+    run outlasts ``limit_s``: a collective that never completes blocks its rank inside a HIP or RCCL call where no
+    Python-level timeout can reach it -- ctypes and torch release the GIL there, so this thread still runs."""
+
+    def __init__(self, limit_s, rank, on_fire=None):
+        import threading
+
+        self.limit_s, self.rank, self.on_fire = limit_s, rank, on_fire
+        self.phase, self.since = "start", time.monotonic()
+        self._stop = threading.Event()
+        if limit_s > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def enter(self, phase):
+        self.phase, self.since = phase, time.monotonic()
+
+    def stop(self):
+        self._stop.set()
+
+    def _run(self):
+        while not self._stop.wait(1.0):
+            waited = time.monotonic() - self.since
+            if waited > self.limit_s:
+                print(f"[bench rank {self.rank}] phase '{self.phase}' has not finished after {waited:.0f} s: taken to be a "
+                      f"hung collective; leaving with exit code {EXIT_PHASE}", file=sys.stderr, flush=True)
+                if self.on_fire is not None:
+                    try:
+                        self.on_fire(self.phase)
+                    except Exception:  # noqa: BLE001 -- nothing may keep the process alive here
+                        pass
+                os._exit(EXIT_PHASE)
+
+
+def agree_any(store, tag, rank, world, mine, wait_s):
+    """True when ANY rank says ``mine``: the ranks' common verdict WITHOUT a GPU collective (the process group's TCP store),
+    for decisions taken exactly when the GPU collectives cannot be trusted -- a rank that timed out on an exchange form
+    must not be waited for in an all-reduce by a rank that finished just inside the limit.  A rank that does not post its
+    verdict within ``wait_s`` counts as hung."""
+    from datetime import timedelta
+
+    store.set(f"mnk_bench/{tag}/{rank}", "1" if mine else "0")
+    verdict = bool(mine)
+    for r in range(world):
+        key = f"mnk_bench/{tag}/{r}"
+        try:
+            store.wait([key], timedelta(seconds=wait_s))
+            verdict = verdict or store.get(key) == b"1"
+        except Exception:  # noqa: BLE001 -- timeout (RuntimeError / DistStoreError by version): that rank never got there
+            verdict = True
+    return verdict
 
 
 def record_bytes(rows):
@@ -636,23 +709,55 @@ def c_stdout_to_stderr():
         os.close(saved)
 
 
-def spawn_ranks(n):
+def wait_ranks(procs, grace_s=30.0, poll_s=0.05):
+    """Waits for ALL rank processes at once.  When one exits non-zero (a rank whose communicator failed leaves with 3
+    while its peers may already sit in a collective that can never complete) the others get ``grace_s`` seconds to
+    finish on their own, are then terminated -- and killed if they ignore that -- so the launcher never blocks on a
+    rank that waits for a dead peer.  Returns the exit codes (negative = ended by that signal)."""
+    deadline = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            return codes
+        if deadline is None and any(c not in (None, 0) for c in codes):
+            deadline = time.monotonic() + grace_s
+            print(f"bench.py: a rank exited non-zero ({codes}); the others have {grace_s:.0f} s to finish", file=sys.stderr)
+        if deadline is not None and time.monotonic() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.monotonic() + 10.0
+            while any(p.poll() is None for p in procs) and time.monotonic() < t_kill:
+                time.sleep(poll_s)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            return [p.wait() for p in procs]
+        time.sleep(poll_s)
+
+
+def spawn_ranks(n, argv=None, grace_s=None):
     """``python bench.py --gpus N`` without a launcher: start N fresh rank processes (one per GPU, the env
     variables torch.distributed.run would set), relay their output -- rank 0 prints the JSON line -- and exit
-    non-zero if any of them does.  Children are new interpreters started BEFORE this process has made any GPU
-    call; nothing is re-exec'ed."""
+    non-zero if any of them does (``wait_ranks``: no rank is waited for forever).  Children are new interpreters started
+    BEFORE this process has made any GPU call; nothing is re-exec'ed.  ``argv``: the children's command line (default:
+    this script with this process's arguments)."""
     import socket
     import subprocess
 
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
+    if argv is None:
+        argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    if grace_s is None:
+        grace_s = float(os.environ.get("MNK_BENCH_GRACE_S", "30"))
     procs = []
     for rank in range(n):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    codes = [p.wait() for p in procs]
+        procs.append(subprocess.Popen(argv, env=env))
+    codes = wait_ranks(procs, grace_s)
     if any(codes):
         sys.exit(f"bench.py: rank exit codes {codes}")
 
@@ -707,25 +812,24 @@ def main():
     if logging:  # a group of the log holds plies 4q..4q+3: chunks (and so the warm-up) end on multiples of 4
         chunk = args.chunk = max(4, chunk - chunk % 4)
     keyframe = max(0, args.keyframe)
-    # two slots (a chunk is gathered while the next one computes); with a log, per slot a message with the chunk-start
-    # state (keyframes) and one without, sharing the slot's record buffers
-    bufs = [roll.alloc(chunk, log_actions=logging, with_state=True) for _ in range(2)]
-    bufs_log = None
-    if logging and keyframe != 1:
-        from selfplay.random_rollout import _msg_views, _msg_words
+    every = args.exchange_every if multi else 1  # chunks per exchange step (one all-gather carries `every` messages)
+    # two slots (a group of `every` chunks is gathered while the next one computes); the chunks of a slot share one set
+    # of record rows (nothing reads them here; a consumer would take them before the slot comes round again)
+    bufs = [roll.alloc(chunk) for _ in range(2)]
+    from selfplay.random_rollout import LogGroup, RolloutRecords, _msg_words, action_log_format
 
-        bufs_log = []
-        for b in bufs:
-            rec = type(b)(planes=b.planes, meta=b.meta)
-            rec.fmt = b.fmt
-            rec.msg = torch.zeros(_msg_words(env.words, nenv, chunk, b.fmt, False), dtype=torch.int64, device=dev)
-            rec.planes0, rec.act, rec.meta0 = _msg_views(rec.msg, env.words, nenv, chunk, b.fmt, False)
-            bufs_log.append(rec)
-    gathered = gathered_log = side = exchange = start_state = None
+    fmt = action_log_format(env.max_moves) if logging else 0
+    side = exchange = start_state = None
+    groups = [{}, {}]   # --gather actions: per slot, state pattern of a group -> LogGroup (send + gathered buffers)
+    rec_groups = None   # --gather records: per slot (planes [J, T, R, N], meta [J, T, N], gathered planes, gathered meta)
     chunk_no = [0]  # chunks played so far (keyframes are counted from the first chunk of the run)
 
     def is_keyframe(c):
         return keyframe == 1 or (keyframe > 1 and c % keyframe == 0)
+
+    def pattern_of(c0):
+        """which of the chunks c0 .. c0 + every - 1 carry their chunk-start state"""
+        return tuple(is_keyframe(c) for c in range(c0, c0 + every))
     if mode != "none":
         side = torch.cuda.Stream(dev)
         if args.backend == "nccl":  # the collective goes through the C ABI (mnk_allgather_records), RCCL over xGMI
@@ -748,18 +852,24 @@ def main():
                           f"rank ({failure}); --allow-fallback runs the all-gather through torch.distributed instead",
                           file=sys.stderr)
                     dist.destroy_process_group()
-                    sys.exit(3)
+                    sys.exit(EXIT_COMM)
                 print(f"[bench rank {rank}] C-ABI communicator unavailable ({failure}); using torch.distributed",
                       file=sys.stderr)
         if mode == "records":
-            gathered = [(torch.empty((world,) + tuple(b.planes.shape), dtype=torch.int64, device=dev),
-                         torch.empty((world,) + tuple(b.meta.shape), dtype=torch.int32, device=dev)) for b in bufs]
+            rec_groups = []
+            for b in bufs:
+                planes = torch.empty((every,) + tuple(b.planes.shape), dtype=torch.int64, device=dev)
+                meta = torch.empty((every,) + tuple(b.meta.shape), dtype=torch.int32, device=dev)
+                rec_groups.append((planes, meta, torch.empty((world,) + tuple(planes.shape), dtype=torch.int64, device=dev),
+                                   torch.empty((world,) + tuple(meta.shape), dtype=torch.int32, device=dev)))
         else:
-            gathered = [GatheredLogs.empty(world, env.words, nenv, chunk, env.max_moves, dev, fmt=bufs[0].fmt,
-                                           with_state=True) for _ in bufs]
-            if bufs_log is not None:
-                gathered_log = [GatheredLogs.empty(world, 0, nenv, chunk, env.max_moves, dev, fmt=bufs[0].fmt,
-                                                   with_state=False) for _ in bufs]
+            # every state pattern the keyframe cadence produces (its period in groups divides `keyframe`)
+            for g in range(max(keyframe, 1)):
+                pat = pattern_of(g * every)
+                for slot in (0, 1):
+                    if pat not in groups[slot]:
+                        groups[slot][pat] = LogGroup(world, env.words, nenv, chunk, fmt, pat, dev, planes=bufs[slot].planes,
+                                                     meta=bufs[slot].meta)
     if exchange is not None:
         exchange.direct = args.allgather == "direct"
     main_stream = torch.cuda.current_stream(dev)
@@ -769,31 +879,51 @@ def main():
 
     timing = [False]
 
+    def gather_group(slot, group):
+        """the exchange step of one group of `every` chunks, enqueued on the side stream"""
+        if logging:
+            group.gather(exchange=exchange, stream=side)
+        else:
+            planes, meta, gp, gm = rec_groups[slot]
+            if exchange is not None:
+                exchange.all_gather(planes.view(-1), gp.view(-1), side)
+                exchange.all_gather(meta.view(-1), gm.view(-1), side)
+            else:
+                dist.all_gather_into_tensor(gp.view(-1), planes.view(-1))
+                dist.all_gather_into_tensor(gm.view(-1), meta.view(-1))
+
     def run_steps(total):
-        """`total` plies per env: ceil(total/chunk) launches; each chunk is all-gathered on the side
-        stream while the next chunk computes.  Returns the number of launches."""
+        """`total` plies per env: total/chunk launches; every `every` chunks their messages are all-gathered (ONE
+        collective) on the side stream while the next group computes.  Returns the number of launches."""
         launches, done, c = 0, 0, 0
+        assert total % (chunk * every) == 0  # a bench step is a whole chunk, an exchange a whole group
+        group = None
         while done < total:
-            t = min(chunk, total - done)
-            slot = c & 1
-            if gather_done[slot] is not None:
-                main_stream.wait_event(gather_done[slot])  # the buffer is free again
-            key = not logging or is_keyframe(chunk_no[0])
+            slot, j = (c // every) & 1, c % every
+            if j == 0:
+                if gather_done[slot] is not None:
+                    main_stream.wait_event(gather_done[slot])  # the slot's buffers are free again
+                if logging:
+                    group = groups[slot][pattern_of(chunk_no[0])]
             chunk_no[0] += 1
-            out = bufs[slot] if key else bufs_log[slot]
-            assert t == chunk  # a bench step is a whole chunk
+            if logging:
+                out = group.records(j)
+            elif mode == "records":
+                out = RolloutRecords(planes=rec_groups[slot][0][j], meta=rec_groups[slot][1][j])
+            else:
+                out = bufs[slot]
             # kernel time: with an exchange step in the loop every launch is bracketed by its own pair of HIP
             # events (the stream also waits for gathers); on one GPU two events around the whole timed region
             # do (per-launch pairs cost ~5 % throughput)
             if timing[0] and mode != "none":
                 ks, ke = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ks.record(main_stream)
-            roll.run(t, out=out)
+            roll.run(chunk, out=out)
             if timing[0] and mode != "none":
                 ke.record(main_stream)
                 kernel_events.append((ks, ke))
             launches += 1
-            if mode != "none":
+            if mode != "none" and j == every - 1:
                 ready = torch.cuda.Event()
                 ready.record(main_stream)
                 with torch.cuda.stream(side):
@@ -801,45 +931,31 @@ def main():
                     if timing[0]:
                         gs = torch.cuda.Event(enable_timing=True)
                         gs.record(side)
-                    if logging:
-                        gather_action_logs(out, out=(gathered if key else gathered_log)[slot], exchange=exchange, stream=side)
-                    else:
-                        gp, gm = gathered[slot]
-                        if exchange is not None:
-                            exchange.all_gather(out.planes.view(-1), gp.view(-1), side)
-                            exchange.all_gather(out.meta.view(-1), gm.view(-1), side)
-                        else:
-                            dist.all_gather_into_tensor(gp.view(-1), out.planes.view(-1))
-                            dist.all_gather_into_tensor(gm.view(-1), out.meta.view(-1))
+                    gather_group(slot, group)
                     ev = torch.cuda.Event(enable_timing=timing[0])
                     ev.record(side)
                     gather_done[slot] = ev
                     if timing[0]:
                         gather_events.append((gs, ev))
-            done += t
+            done += chunk
             c += 1
         if mode != "none":
             main_stream.wait_stream(side)
         return launches
 
     def exchange_alone_ms(reps=8, limit_s=60.0):
-        """`reps` exchange steps of the every-chunk message back to back on the side stream with nothing else running,
-        by HIP events (this rank's mean); None if they do not finish within `limit_s` -- the caller then prints its
-        line and leaves without touching a collective again (a first run of an exchange form on a new node must not be
-        able to hang the job)."""
-        src = (bufs_log or bufs)[0]
+        """`reps` exchange steps of the every-group message back to back on the side stream with nothing else running,
+        by HIP events (this rank's mean); None if they do not finish within `limit_s` -- the caller then agrees with the
+        other ranks (over the TCP store, not the GPU) that the form hung, prints its line and leaves with a non-zero
+        exit code without touching a collective again."""
+        group = groups[0][min(groups[0], key=sum)] if logging else None  # the group with the fewest keyframes in it
         events = []
         barrier()
         with torch.cuda.stream(side):
             for _ in range(reps):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(side)
-                if logging:
-                    gather_action_logs(src, out=(gathered_log or gathered)[0], exchange=exchange, stream=side)
-                else:
-                    gp, gm = gathered[0]
-                    exchange.all_gather(src.planes.view(-1), gp.view(-1), side)
-                    exchange.all_gather(src.meta.view(-1), gm.view(-1), side)
+                gather_group(0, group)
                 b.record(side)
                 events.append((a, b))
         t_start = time.perf_counter()
@@ -862,10 +978,21 @@ def main():
         # env), outside the timed region; keeping it current is the receivers' job (replay_shard(..., state=...))
         start_state = gather_start_state(env, exchange=exchange, stream=main_stream)
         torch.cuda.synchronize(dev)
+    # multi-rank runs: no phase may block for ever (a collective that never completes cannot be timed out from Python)
+    line = [None]  # the JSON line as far as it has been assembled: what a watchdog exit still prints on rank 0
+
+    def print_partial(phase):
+        if rank == 0 and line[0] is not None:
+            line[0]["aborted_in_phase"] = phase
+            print(json.dumps(line[0]), flush=True)
+    watchdog = PhaseWatchdog(args.phase_timeout if multi else 0.0, rank, print_partial)
+    watchdog.enter("set-up launches")
     run_steps(args.settle * chunk)
     barrier()
+    watchdog.enter("warm-up")
     run_steps(args.warmup * chunk)
     barrier()
+    watchdog.enter("timed region")
     timing[0] = True
     region0, region1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -888,6 +1015,7 @@ def main():
     # SURVEY.md section 8d asks for repetitions: four more timed regions of the same K steps (not part of `value`)
     reps = [value]
     timing[0] = False
+    watchdog.enter("repetitions")
     for _ in range(4):
         barrier()
         r0 = time.perf_counter()
@@ -905,9 +1033,11 @@ def main():
         def run_compute_only(total):
             done = 0
             while done < total:
-                roll.run(chunk, out=(bufs_log or bufs)[(done // chunk) & 1])
+                roll.run(chunk, out=(groups[(done // chunk) & 1][min(groups[0], key=sum)].records(0) if logging
+                                     else bufs[(done // chunk) & 1]))
                 done += chunk
 
+        watchdog.enter("compute-only run")
         barrier()
         c0 = time.perf_counter()
         run_compute_only(args.steps * chunk)
@@ -921,8 +1051,9 @@ def main():
     plies_per_launch = chunk
     rows = mnk_hip.record_words(m, n)
     alg_bytes = nenv * (plies_per_launch * record_bytes(rows) + 2 * state_bytes(words))
-    launch_s = dev_ms * 1e-3 / launches
+    launch_s = dev_ms * 1e-3 / launches   # HIP events on the kernel's stream over the timed region
     achieved = alg_bytes / launch_s / 1e9
+    achieved_wall = alg_bytes / (dt / launches) / 1e9  # the interval `value` is computed from (slowest rank's wall clock)
     survey_b_roll = state_bytes(words) + 8 * words + 4 + state_bytes(words)  # 92 B at 9x9
     out = {
         "metric": f"env-steps/sec {m}x{n}x{k}, {nenv} parallel envs/GPU, random-policy rollout",
@@ -951,7 +1082,7 @@ def main():
         # variant that mode implies, and the transport of the collective
         "gather": mode,
         "kernel_variant": "records + action log " + {1: "(one byte per action)", 2: "(two bytes per action)", 3: "(7-bit stream)",
-                                                     4: "(a byte and a bit per action)"}[bufs[0].fmt] if logging
+                                                     4: "(a byte and a bit per action)"}[fmt] if logging
                           else "records only (no action log)",
         "transport": None,
         "roofline": {
@@ -960,6 +1091,13 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
+            # the same fraction on both clocks of this line: `frac` = frac_kernel_events (HIP events around the timed
+            # region on the kernel's stream, what the contract asks for); frac_wall = from `ms_per_step`, the barrier-to-
+            # barrier wall clock `value` is computed from (it contains the last launch's drain and, with an exchange
+            # step, the waits for it): frac_wall <= frac_kernel_events by construction
+            "frac_kernel_events": achieved / HBM_PEAK_GBS,
+            "frac_wall": achieved_wall / HBM_PEAK_GBS,
+            "achieved_wall": achieved_wall,
             "traffic": PMC_TRAFFIC.get((args.board, nenv, chunk), (None, None))[0],
             "traffic_unit": "bytes per launch",
             "traffic_source": PMC_TRAFFIC.get((args.board, nenv, chunk), (None, None))[1],
@@ -974,13 +1112,13 @@ def main():
     }
     if mode != "none":
         if logging:
-            key_bytes = bufs[0].msg.numel() * 8
-            log_bytes = bufs_log[0].msg.numel() * 8 if bufs_log is not None else key_bytes
+            key_bytes = _msg_words(env.words, nenv, chunk, fmt, True) * 8
+            log_bytes = _msg_words(env.words, nenv, chunk, fmt, False) * 8
             share = 1.0 if keyframe == 1 else (0.0 if keyframe == 0 else 1.0 / keyframe)
             msg_bytes = share * key_bytes + (1.0 - share) * log_bytes  # average per chunk
         else:
             msg_bytes = bufs[0].planes.numel() * 8 + bufs[0].meta.numel() * 4
-        mean_ms = sum(gather_ms) / max(len(gather_ms), 1)
+        mean_ms = sum(gather_ms) / max(len(gather_ms), 1)  # per exchange step = per `every` chunks
         worst = torch.tensor([mean_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(worst, op=dist.ReduceOp.MAX)
         mean_ms = float(worst.item())
@@ -1002,16 +1140,18 @@ def main():
                          else f"torch.distributed {args.backend}" + (" (FALLBACK: the C-ABI communicator failed)"
                                                                      if args.backend == "nccl" else ""),
             "bytes_per_rank_per_chunk": msg_bytes,
+            "chunks_per_exchange": every,                 # --exchange-every: one all-gather carries this many chunks' messages
+            "bytes_per_rank_per_exchange": msg_bytes * every,
             "bytes_per_env_step": msg_bytes / (nenv * chunk),
-            "allgather_ms": mean_ms,                      # slowest rank's mean, HIP events on the side stream
-            "recv_GBps_per_rank": (world - 1) * msg_bytes / (mean_ms * 1e-3) / 1e9 if mean_ms else None,
+            "allgather_ms": mean_ms,                      # per exchange step; slowest rank's mean, HIP events on the side stream
+            "recv_GBps_per_rank": (world - 1) * msg_bytes * every / (mean_ms * 1e-3) / 1e9 if mean_ms else None,
             # every peer's message reaches this rank over that peer's own xGMI link (fully connected mesh): the
             # per-link rate is one message per all-gather time
-            "per_link_GBps": msg_bytes / (mean_ms * 1e-3) / 1e9 if mean_ms else None,
+            "per_link_GBps": msg_bytes * every / (mean_ms * 1e-3) / 1e9 if mean_ms else None,
             "xgmi_link_peak_GBps": 153.0,
             "compute_ms_per_chunk": compute_ms,
             "exposed_ms_per_chunk": exposed_ms,           # step time minus the compute-only step time
-            "overlap_fraction": max(0.0, 1.0 - exposed_ms / mean_ms) if mean_ms else None,
+            "overlap_fraction": max(0.0, 1.0 - exposed_ms * every / mean_ms) if mean_ms else None,
         }
     if args.rehearse_exchange and world == 1:
         out["rehearsal"] = "the multi-GPU code path on one GPU (a one-rank communicator): not a measurement"
@@ -1023,17 +1163,31 @@ def main():
     # both forms of the exchange step alone (rank 0's clock): the one of the timed loop first, the other one last and
     # under a watchdog, because the driver's multi-GPU run is the first time it meets more than one GPU
     alone = None
-    exchange_hung = False
+    exchange_hung = None  # name of the exchange form that never finished, on ANY rank
+    line[0] = out
     if exchange is not None:
         alone = {}
+        store = dist.distributed_c10d._get_default_store()
         for form in ((False, True) if not exchange.direct else (True, False)):
+            name = "direct_sendrecv" if form else "ncclAllGather"
+            # the host side of the enqueue can block too (RCCL's group end): the watchdog covers that
+            watchdog.enter(f"exchange form alone: {name}")
             exchange.direct = form
-            ms = exchange_alone_ms()
-            alone["direct_sendrecv_ms" if form else "ncclAllGather_ms"] = ms
-            if ms is None:
-                exchange_hung = True
+            ms = exchange_alone_ms(limit_s=args.alone_limit)
+            if os.environ.get("MNK_BENCH_FAKE_HANG") == name:  # tests: take this form to have hung on this rank
+                ms = None
+            alone[name + "_ms"] = ms
+            # one verdict for all ranks, over the TCP store: a rank that finished must not wait in a GPU collective for
+            # one that did not
+            if agree_any(store, f"alone/{name}", rank, world, ms is None, args.alone_limit + 30.0):
+                exchange_hung = name
+                print(f"[bench rank {rank}] exchange form {name} alone did not finish within {args.alone_limit:.0f} s on "
+                      f"{'this rank' if ms is None else 'another rank'}; leaving with exit code {EXIT_HUNG}", file=sys.stderr)
                 break
         exchange.direct = args.allgather == "direct"
+    if exchange_hung:
+        out["exchange_hung"] = exchange_hung
+    watchdog.enter("re-run with the direct form" if exchange is not None else "report")
     if alone is not None and not exchange_hung and args.allgather == "auto":
         # every rank decides on the same numbers: the slowest rank's
         both = torch.tensor([alone["ncclAllGather_ms"], alone["direct_sendrecv_ms"]], dtype=torch.float64, device=dev)
@@ -1079,13 +1233,15 @@ def main():
         else:
             out["exchange"]["auto"] = "kept ncclAllGather: the direct form alone was not 10 % faster on the slowest rank"
     if alone is not None:
-        alone["what"] = ("the exchange step of the every-chunk message alone (8 back to back, nothing else running, this "
-                         "rank's HIP events); null = did not finish within 60 s")
+        alone["what"] = (f"the exchange step ({every} chunk message{'s' if every > 1 else ''} per all-gather, the group with the "
+                         "fewest keyframes) alone: 8 back to back, nothing else running, this rank's HIP events; null = did "
+                         f"not finish within {args.alone_limit:.0f} s (the run then leaves with exit code {EXIT_HUNG})")
         out["exchange"]["alone"] = alone
     if rank == 0:
-        stats = roll.stats.tolist()
-        out["rollout_stats"] = {"episodes": stats[0], "mean_plies": stats[4] / max(stats[0], 1),
-                                "draw_rate": stats[3] / max(stats[0], 1)}
+        if not exchange_hung:  # (a device read: not with a collective stuck on the GPU)
+            stats = roll.stats.tolist()
+            out["rollout_stats"] = {"episodes": stats[0], "mean_plies": stats[4] / max(stats[0], 1),
+                                    "draw_rate": stats[3] / max(stats[0], 1)}
         out["gpu"] = gpu_identity(dev)
         if not multi and not args.no_api_path:
             out["roofline"]["measured_write_ceiling_GBps"] = write_ceiling_GBps(dev, nenv, chunk, rows)
@@ -1119,15 +1275,18 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if exchange_hung:  # an exchange form never finished: no synchronisation or collective can be trusted any more
-        sys.stdout.flush()
-        os._exit(0)
+    if exchange_hung:  # an exchange form never finished: no synchronisation or collective can be trusted any more --
+        sys.stdout.flush()  # the line is out; leave NON-ZERO (the driver's rc must say that this run hung) and at once
+        sys.stderr.flush()
+        os._exit(EXIT_HUNG)
+    watchdog.enter("teardown")
     if exchange is not None:
         torch.cuda.synchronize(dev)
         exchange.close()
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+    watchdog.stop()
 
 
 if __name__ == "__main__":

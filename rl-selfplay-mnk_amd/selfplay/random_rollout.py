@@ -301,6 +301,74 @@ def gather_action_logs(rec: RolloutRecords, group=None, out: Optional[GatheredLo
     return out
 
 
+class LogGroup:
+    """J consecutive chunks' exchange messages laid end to end in ONE flat buffer, so that J chunks cost one
+    all-gather of J times the bytes instead of J all-gathers (``bench.py --exchange-every J``: RCCL's per-call cost and
+    the small-message regime of xGMI are what a larger message amortises).  Chunk j's message keeps the layout of
+    ``_msg_views`` (chunk-start state | log | meta) and is self-contained or log-only according to ``with_state[j]``
+    -- a keyframed stream puts a state into the chunks the keyframe cadence names, wherever they fall in the group.
+
+    Sender: ``records(j)`` is the ``RolloutRecords`` chunk j's launch writes (its ``msg`` is a view into ``send``; the
+    record rows ``planes`` / ``meta`` are shared by the chunks of the group unless ``own_records``).  Receiver:
+    ``gather()`` all-gathers ``send`` into ``recv`` [world, L]; ``logs(j)`` are chunk j's ``GatheredLogs`` (views of
+    ``recv``), ready for ``replay_shard`` / ``KeyframedLogs.push``."""
+
+    def __init__(self, world: int, words: int, nenv: int, steps: int, fmt: int, with_state, device, planes=None,
+                 meta=None, rows: int = 0):
+        self.world, self.words, self.nenv, self.steps, self.fmt = world, words, nenv, steps, fmt
+        self.with_state = tuple(bool(s) for s in with_state)
+        sizes = [_msg_words(words, nenv, steps, fmt, s) for s in self.with_state]
+        self.offsets = [sum(sizes[:j]) for j in range(len(sizes) + 1)]
+        self.send = torch.zeros(self.offsets[-1], dtype=torch.int64, device=device)
+        self.recv = torch.empty((world, self.offsets[-1]), dtype=torch.int64, device=device)
+        self._recs, self._logs = [], []
+        for j, state in enumerate(self.with_state):
+            lo, hi = self.offsets[j], self.offsets[j + 1]
+            msg = self.send[lo:hi]
+            planes0, act, meta0 = _msg_views(msg, words, nenv, steps, fmt, state)
+            rec = RolloutRecords(planes=planes, meta=meta, act=act, meta0=meta0, planes0=planes0, msg=msg, fmt=fmt)
+            if planes is None and rows:  # records of its own (tests; the bench shares one set per slot)
+                rec.planes = torch.empty((steps, rows, nenv), dtype=torch.int64, device=device)
+                rec.meta = torch.empty((steps, nenv), dtype=torch.int32, device=device)
+            self._recs.append(rec)
+            got = self.recv[:, lo:hi]  # [world, L_j], row stride = the whole group's length
+            gp0, gact, gm0 = _msg_views(got, words, nenv, steps, fmt, state)
+            # the views must alias `recv` (a silent copy would be read before the all-gather has filled it)
+            assert gact.data_ptr() == got.data_ptr() + (_msg_layout(words, nenv, steps, fmt, state)[0]) * 8
+            self._logs.append(GatheredLogs(planes0=gp0, meta0=gm0, act=gact, steps=steps, msg=got, fmt=fmt))
+
+    def __len__(self) -> int:
+        return len(self.with_state)
+
+    @property
+    def bytes(self) -> int:
+        """bytes one rank sends per exchange"""
+        return self.send.numel() * 8
+
+    def records(self, j: int) -> RolloutRecords:
+        return self._recs[j]
+
+    def logs(self, j: int) -> GatheredLogs:
+        return self._logs[j]
+
+    def gather(self, group=None, exchange=None, stream=None) -> "LogGroup":
+        """ONE all-gather of the J messages (``exchange``: the C ABI's RCCL communicator, enqueued on ``stream``;
+        else ``torch.distributed``)."""
+        if exchange is not None:
+            assert exchange.world == self.world
+            exchange.all_gather(self.send, self.recv.view(-1), stream)
+        else:
+            import torch.distributed as dist
+
+            if dist.is_initialized() and dist.get_world_size(group) > 1:
+                assert dist.get_world_size(group) == self.world
+                dist.all_gather_into_tensor(self.recv.view(-1), self.send, group=group)
+            else:
+                assert self.world == 1
+                self.recv[0].copy_(self.send)
+        return self
+
+
 def replay_shard(logs: GatheredLogs, shard: int, m: int, n: int, k: int, err: Optional[torch.Tensor] = None,
                  out: Optional[RolloutRecords] = None, scratch=None, state: Optional[ReplayState] = None,
                  record: bool = True) -> Optional[RolloutRecords]:

@@ -173,3 +173,75 @@ def test_gather_is_identity_for_one_rank(tmp_path):
         assert gather_records(rec) is rec
     finally:
         dist.destroy_process_group()
+
+
+def _group_worker(rank, world, port, m, n, k, nenv, steps, chunks, seed, out_dir):
+    """``bench.py --exchange-every J`` on the CPU: J chunks' messages (a keyframe + J-1 logs, or all keyframes) travel
+    in ONE all-gather (``selfplay.random_rollout.LogGroup``); what every rank reads out of the gathered buffer are the
+    chunk-start states and logs of every shard, chunk by chunk."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    entry._ensure_path()
+    from oracle.env_torch import OracleVectorEnv
+    from oracle.packing import pack_boards, words_per_plane
+    from oracle.rollout import encode_action_log, random_rollout
+    from selfplay.random_rollout import ACT_BITS7, ACT_U8, KeyframedLogs, LogGroup, unpack_action_log
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        words = words_per_plane(m, n)
+        fmt = ACT_BITS7 if m * n <= 128 else ACT_U8
+        got = {}
+        for name, pattern in (("key_first", (True,) + (False,) * (chunks - 1)), ("all_keys", (True,) * chunks)):
+            env = OracleVectorEnv(m, n, k, nenv)
+            group = LogGroup(world, words, nenv, steps, fmt, pattern, torch.device("cpu"))
+            assert len(group) == chunks and group.bytes == group.send.numel() * 8
+            for j in range(chunks):
+                rec = group.records(j)
+                assert (rec.planes0 is not None) == pattern[j]
+                if pattern[j]:
+                    rec.planes0.copy_(torch.from_numpy(pack_boards(env.boards.numpy(), m, n).view(np.int64)))
+                    rec.meta0.copy_((env.current_player.to(torch.int32) | (env.move_counts.to(torch.int32) << 1)))
+                _, meta, _ = random_rollout(env, seed=seed, step0=j * steps, steps=steps, env_id0=rank * nenv)
+                rec.act.copy_(torch.from_numpy(encode_action_log((meta & 0xFFFF).astype(np.int64), fmt).view(np.int32)))
+            group.gather()
+            # the receiving side of a keyframed stream takes the chunks as they are
+            stream = KeyframedLogs(m, n, k)
+            for j in range(chunks):
+                stream.push(group.logs(j))
+            assert stream.chunks() == (chunks if name == "key_first" else 1)
+            got[name + "_acts"] = torch.stack([torch.cat([unpack_action_log(group.logs(j).act[r], steps, fmt)
+                                                          for r in range(world)], dim=1) for j in range(chunks)]).numpy()
+            got[name + "_planes0"] = torch.stack([torch.cat([group.logs(j).planes0[r] for r in range(world)], dim=2)
+                                                  for j in range(chunks) if pattern[j]]).numpy()
+            got[name + "_meta0"] = torch.stack([torch.cat([group.logs(j).meta0[r] for r in range(world)])
+                                                for j in range(chunks) if pattern[j]]).numpy()
+        np.savez(os.path.join(out_dir, f"group{rank}.npz"), **got)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("m,n,k,nenv,steps,chunks", [(3, 3, 3, 12, 8, 2), (9, 9, 5, 10, 20, 3)])
+def test_grouped_exchange_equals_the_single_process_result(tmp_path, m, n, k, nenv, steps, chunks):
+    """--exchange-every J: one all-gather per J chunks == what one process holding all the envs plays."""
+    world, seed = 2, 5
+    mp.spawn(_group_worker, args=(world, _free_port(), m, n, k, nenv, steps, chunks, seed, str(tmp_path)), nprocs=world,
+             join=True)
+    from oracle.env_torch import OracleVectorEnv
+    from oracle.packing import pack_boards
+    from oracle.rollout import random_rollout
+
+    env = OracleVectorEnv(m, n, k, world * nenv)
+    acts, planes0, meta0 = [], [], []
+    for j in range(chunks):
+        planes0.append(pack_boards(env.boards.numpy(), m, n).view(np.int64))
+        meta0.append((env.current_player.to(torch.int32) | (env.move_counts.to(torch.int32) << 1)).numpy())
+        _, meta, _ = random_rollout(env, seed=seed, step0=j * steps, steps=steps)
+        acts.append((meta & 0xFFFF).astype(np.int64))
+    for rank in range(world):
+        got = np.load(tmp_path / f"group{rank}.npz")
+        for name in ("key_first", "all_keys"):
+            assert np.array_equal(got[name + "_acts"], np.stack(acts)), (rank, name)
+            keys = range(chunks) if name == "all_keys" else (0,)
+            assert np.array_equal(got[name + "_planes0"], np.stack([planes0[j] for j in keys])), (rank, name)
+            assert np.array_equal(got[name + "_meta0"], np.stack([meta0[j] for j in keys])), (rank, name)

@@ -186,7 +186,8 @@ def test_two_ranks_exchange_keyframed_logs_and_rebuild_each_others_records(m, n,
         assert f"RANK_OK {rank}" in out, out[-2000:] + err[-4000:]
 
 
-@pytest.mark.parametrize("extra", [[], ["--allgather", "direct", "--keyframe", "1"], ["--gather", "records"], ["FORCE_SWITCH"]])
+@pytest.mark.parametrize("extra", [[], ["--allgather", "direct", "--keyframe", "1"], ["--gather", "records"], ["FORCE_SWITCH"],
+                                   ["--exchange-every", "2"], ["--exchange-every", "2", "--gather", "records"]])
 def test_bench_multi_gpu_code_path_rehearsed_on_one_gpu(extra):
     """``bench.py --rehearse-exchange``: the code path the driver's multi-GPU run takes -- process group (RCCL), the C ABI's
     communicator, the exchange step on a side stream overlapping the next chunk, both exchange forms timed alone under a
@@ -214,8 +215,50 @@ def test_bench_multi_gpu_code_path_rehearsed_on_one_gpu(extra):
         assert ("direct" in ex["transport"]) == ("direct" in extra)
     assert ex["alone"]["ncclAllGather_ms"] > 0 and ex["alone"]["direct_sendrecv_ms"] > 0
     assert d["value"] > 0 and d["value_without_exchange"] > 0 and ex["allgather_ms"] > 0
+    every = 2 if "--exchange-every" in extra else 1
+    assert ex["chunks_per_exchange"] == every and ex["bytes_per_rank_per_exchange"] == every * ex["bytes_per_rank_per_chunk"]
+    r = d["roofline"]
+    assert r["frac"] == r["frac_kernel_events"] and 0 < r["frac_wall"] <= 1.02 * r["frac_kernel_events"]
     if "--allgather" not in extra:
         assert ex["alone"]["slowest_rank"]["ncclAllGather_ms"] > 0 and "auto" in ex
         if force:
             assert ("with_ncclAllGather" in ex) != ("with_direct_sendrecv" in ex)
             assert ("direct" in ex["transport"]) == ("with_ncclAllGather" in ex)
+
+
+@pytest.mark.parametrize("form", ["ncclAllGather", "direct_sendrecv"])
+def test_bench_leaves_non_zero_when_an_exchange_form_hangs(form):
+    """The branch a hung exchange form takes (``exchange_alone_ms`` -> None, here faked for one form): the ranks agree over
+    the TCP store, rank 0 still prints its line -- with ``exchange_hung`` naming the form -- and the process leaves with
+    exit code 4, never 0: the driver's rc must say that the run did not end well."""
+    import json
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MNK_BENCH_FAKE_HANG=form)
+    for var in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(var, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-exchange", "--steps", "4", "--warmup", "2",
+                          "--settle", "4", "--envs", "4096"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 4, (out.returncode, out.stderr[-3000:])
+    assert f"exchange form {form} alone did not finish" in out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["exchange_hung"] == form and d["exchange"]["alone"][form + "_ms"] is None and d["value"] > 0
+
+
+def test_bench_two_gloo_ranks_exchange_every_two_chunks():
+    """``bench.py --gpus 2 --exchange-every 2`` with self-spawned ranks (gloo; both on this box's GPU): one all-gather per two
+    chunks carrying both messages, the launcher relaying rank 0's line and the ranks' exit codes."""
+    import json
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for var in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(var, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--exchange-every",
+                          "2", "--keyframe", "4", "--steps", "8", "--warmup", "2", "--settle", "4", "--envs", "4096"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    ex = d["exchange"]
+    assert d["n_gpus"] == 2 and ex["chunks_per_exchange"] == 2 and ex["keyframe_every_chunks"] == 4
+    assert ex["bytes_per_env_step"] == pytest.approx(0.875 + 36 / (256 * 4), abs=2e-3)
