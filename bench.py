@@ -489,13 +489,106 @@ def selfplay_object(m, n, k, nenv, seed, dev, steps=64):
     out.update({
         "graphed_agent_steps_per_s": nenv / (ms * 1e-3),
         "graphed_env_side_us_per_agent_step": ms * 1e3,
-        "launches_per_agent_step": 2,
+        "launches_per_agent_step": 1,  # round 4: the agent's draw is folded into the step kernel (mnk_selfplay_step_random_logits)
         "alg_bytes_per_agent_step": alg,
         "achieved_GBps": alg * nenv / (ms * 1e-3) / 1e9,
         "frac_of_hbm_peak": alg * nenv / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "survey_B_agent_bytes": 2 * (16 * words + 4 + 8 * words + 4) + 17 * c + 15,
     })
     return out
+
+
+def train_cadence(nenv, steps=64, rollouts=12, m=9, n=9, k=5, dev="cuda:0"):
+    """The rollout loop at the REFERENCE's cadence: a new opponent -- a deepcopy of the agent's network -- before every
+    rollout (train.py:106-114), `steps` agent-steps per rollout, network agent against network opponent (a small
+    BatchNorm-free conv policy: 3 x conv3x3(32) + 1x1 heads).  us per agent-step of
+      (a) the reference-shaped eager loop: net -> Categorical.sample / log_prob -> wrapper.step -> buffer.add
+          (alg/ppo.py:93-108), set_opponent(FusedNNPolicy(deepcopy(net))) before each rollout, the sink attached;
+      (b) ONE captured GraphedRollout whose opponent is swapped in place (set_opponent_weights: no capture);
+      (c) a recapture before every rollout (what round 3 needed: an eager warm-up rollout + a capture)."""
+    import copy
+
+    import torch.nn as nn
+
+    from alg.rollout_buffer import RolloutBuffer
+    from env.torch_vector_mnk_env import TorchVectorMnkEnv
+    from selfplay.graphed import GraphedRollout
+    from selfplay.policy import FusedNNPolicy
+    from selfplay.torch_self_play_wrapper import TorchSelfPlayWrapper
+
+    c = m * n
+
+    class ConvNet(nn.Module):
+        def __init__(self, width=32):
+            super().__init__()
+            self.body = nn.Sequential(nn.Conv2d(2, width, 3, padding=1), nn.ReLU(), nn.Conv2d(width, width, 3, padding=1),
+                                      nn.ReLU(), nn.Conv2d(width, width, 3, padding=1), nn.ReLU())
+            self.pi = nn.Sequential(nn.Conv2d(width, 2, 1), nn.Flatten(), nn.Linear(2 * c, c))
+            self.v = nn.Sequential(nn.Conv2d(width, 1, 1), nn.Flatten(), nn.Linear(c, 1), nn.Tanh())
+
+        def forward(self, obs, action_mask=None):
+            f = self.body(obs)
+            logits = self.pi(f)
+            if action_mask is not None:
+                logits = torch.where(action_mask.bool(), logits, torch.full_like(logits, -torch.inf))
+            return torch.distributions.Categorical(logits=logits, validate_args=False), self.v(f)
+
+    torch.manual_seed(0)
+    net = ConvNet().to(dev).eval()
+
+    def make():
+        w = TorchSelfPlayWrapper(TorchVectorMnkEnv(m, n, k, nenv, device=dev), seed=1)
+        w.set_opponent(FusedNNPolicy(copy.deepcopy(net), seed=2))
+        return w
+
+    w = make()
+    buf = RolloutBuffer(steps, nenv, (2, m, n), c, device=dev)
+    w.attach_sink(buf)
+    obs, _ = w.reset()
+    state = {"obs": obs}
+
+    def eager_rollout(j):
+        w.set_opponent(FusedNNPolicy(copy.deepcopy(net), seed=100 + j))  # train.py:110-114
+        for _ in range(steps):
+            o = state["obs"]
+            with torch.no_grad():
+                dist, values = net(o["observation"], o["action_mask"])
+                a = dist.sample()
+                lp = dist.log_prob(a)
+            nxt, r, term, trunc, _ = w.step(a)
+            buf.add(o["observation"], a, r, values, lp, term | trunc, o["action_mask"])
+            state["obs"] = nxt
+        buf.reset()  # (after the rollout, as ppo.py:148: the carried-over observation sits in the spill row)
+
+    def wall(fn):
+        fn(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for j in range(rollouts):
+            fn(1 + j)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / (rollouts * steps) * 1e6
+
+    t_eager = wall(eager_rollout)
+    buf2 = RolloutBuffer(steps, nenv, (2, m, n), c, device=dev)
+    roll = GraphedRollout(make(), buf2, net, seed=3)
+    graph = roll.graph
+
+    def swap_rollout(j):
+        roll.set_opponent_weights(net, seed=100 + j)
+        roll.run()
+        buf2.reset()
+
+    t_swap = wall(swap_rollout)
+    assert roll.graph is graph  # no capture happened
+
+    def recapture_rollout(j):
+        roll.wrapper.set_opponent(FusedNNPolicy(copy.deepcopy(net), seed=100 + j))
+        roll.recapture()  # (one real rollout + a capture)
+        buf2.reset()
+
+    t_recap = wall(recapture_rollout)
+    return t_eager, t_swap, t_recap
 
 
 def with_action_log_rate(roll, chunk, steps):
@@ -1262,6 +1355,14 @@ def main():
             out["replay_env_steps_per_s"] = replay_rate(env, roll, chunk)
             out["with_action_log"] = with_action_log_rate(roll, chunk, args.steps)
             out["selfplay"] = selfplay_object(m, n, k, nenv, args.seed, dev)
+            # the reference trains at 384 envs with a NEW opponent before every rollout (train.py:106-114, :246)
+            te, ts, tr = train_cadence(384, rollouts=6, m=m, n=n, k=k, dev=str(dev))
+            out["selfplay"]["train_cadence_384_envs"] = {
+                "what": "64 agent-steps per rollout, network agent vs network opponent (3 x conv3x3(32)), a new opponent "
+                        "(deepcopy of the agent) before every rollout: us per agent-step",
+                "eager_reference_loop_us": te, "one_graph_inplace_opponent_swap_us": ts, "recapture_per_rollout_us": tr,
+                "speedup_swap_vs_eager": te / ts, "agent_steps_per_s_swap": 384 / ts * 1e6,
+                "env_side_launches_per_agent_step": 2}
             # BASELINE config 3 proper (conv policy as agent, pool of 4 network opponents), a short run of what
             # `--mode selfplay` measures at length: the caller-side networks are >99 % of it
             torch.cuda.empty_cache()

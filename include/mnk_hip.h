@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define MNK_ABI_VERSION 4
+#define MNK_ABI_VERSION 5
 
 /* status codes (host-side argument checks) */
 #define MNK_OK 0
@@ -198,9 +198,12 @@ int mnk_sample_legal(const uint64_t* planes, int64_t N, int m, int n, uint64_t s
  * reads only the mask.  deterministic != 0 -> argmax over legal cells (policy.py:48-49); else an inverse-CDF draw
  * from softmax(masked logits) with one Philox uniform per row (stream MNK_STREAM_SAMPLE).
  * All-masked row -> uniform over C (cnn.py:76-77).
- * logp (optional) = log-probability of the chosen action under the masked softmax (f32 arithmetic). */
+ * logp (optional) = log-probability of the chosen action under the masked softmax (f32 arithmetic).
+ * seed_dev (optional): device pointer to a u64 that REPLACES `seed` -- the sampler's Philox key in device memory, so a
+ * sampler captured into a hipGraph can be re-keyed without a new capture (a fresh opponent before every rollout,
+ * train.py:106-114).  Row i draws from Philox(seed, env_id0 + i, step [+ *step_dev], MNK_STREAM_SAMPLE). */
 int mnk_sample_logits(const void* logits, int logits_dtype, const uint8_t* mask, int64_t N, int C, uint64_t seed,
-                      uint64_t step, const uint64_t* step_dev, int64_t env_id0, int deterministic,
+                      const uint64_t* seed_dev, uint64_t step, const uint64_t* step_dev, int64_t env_id0, int deterministic,
                       int64_t* actions, float* logp, void* stream);
 
 /* ---- selfplay/torch_self_play_wrapper.py:32-67 step(), split around the opponent forward ----
@@ -242,6 +245,45 @@ int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m,
                              uint8_t* legal_mask, uint64_t* packed_obs,
                              int32_t* err, float* ep_return, int32_t* ep_length, int64_t* ep_stats,
                              uint32_t flags, void* stream);
+
+/* ---- the step kernels with the masked draw folded in ("[masked sample + opp ply + zero-sum
+ * merge + canonical obs]" in one launch).  Each takes, in place of the int64 moves of its plain form, what
+ * mnk_sample_logits takes -- logits [N][C] (NULL = uniform over the mask), logits_dtype, mask u8[N][C], the SAMPLER's
+ * Philox key and position (sample_seed / sample_seed_dev / sample_step / sample_step_dev / sample_env_id0: independent of
+ * the wrapper's own seed / step / env_id0 that follow), deterministic -- draws every row's move in the kernel and plays it:
+ *   mnk_selfplay_pre_logits          the AGENT's move from its policy head (selfplay/policy.py:46-52, cnn.py:69-79) with its
+ *                                    log-probability (alg/ppo.py:96-97), then wrapper:39-59;
+ *   mnk_selfplay_post_logits         the OPPONENT's reply from its head on the view `pre` wrote (wrapper:83-96), then the
+ *                                    merge and the agent's canonical view (wrapper:59-65, :99-112);
+ *   mnk_selfplay_step_random_logits  the agent's move as in pre, the uniformly random opponent, everything else: one launch
+ *                                    per agent-step.
+ * `actions` (required) / `logp` (optional) receive the drawn moves and their log-probabilities for ALL N rows (rows whose
+ * move is not played -- pending resets, no reply needed -- still draw: the rollout buffer stores them, alg/ppo.py:104).
+ * Bit-identical to mnk_sample_logits followed by the plain form.  One launch on 3x3x3, 9x9x5, 13x13x5, 15x15x5 and 19x19x5;
+ * other boards take the two launches inside the call.  A network-vs-network agent-step is 2 env-side launches (was 4). */
+int mnk_selfplay_pre_logits(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const void* logits,
+                            int logits_dtype, const uint8_t* mask, uint64_t sample_seed, const uint64_t* sample_seed_dev,
+                            uint64_t sample_step, const uint64_t* sample_step_dev, int64_t sample_env_id0, int deterministic,
+                            int64_t* actions, float* logp, const uint8_t* pending, int64_t* agent_side,
+                            const int64_t* forced_side, uint64_t seed, uint64_t step, const uint64_t* step_dev,
+                            int64_t env_id0, float* rewards, uint8_t* terminated, uint8_t* sp_flags, void* opp_obs,
+                            int obs_dtype, uint8_t* opp_mask, int32_t* err, uint32_t flags, void* stream);
+int mnk_selfplay_post_logits(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const void* opp_logits,
+                             int logits_dtype, const uint8_t* opp_mask, uint64_t sample_seed, const uint64_t* sample_seed_dev,
+                             uint64_t sample_step, const uint64_t* sample_step_dev, int64_t sample_env_id0, int deterministic,
+                             int64_t* opp_actions, float* opp_logp, const uint8_t* sp_flags, const int64_t* agent_side,
+                             float* rewards, uint8_t* terminated, uint8_t* pending, void* obs, int obs_dtype,
+                             uint8_t* legal_mask, uint64_t* packed_obs, int32_t* err, float* ep_return, int32_t* ep_length,
+                             int64_t* ep_stats, uint32_t flags, void* stream);
+int mnk_selfplay_step_random_logits(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const void* logits,
+                                    int logits_dtype, const uint8_t* mask, uint64_t sample_seed,
+                                    const uint64_t* sample_seed_dev, uint64_t sample_step, const uint64_t* sample_step_dev,
+                                    int64_t sample_env_id0, int deterministic, int64_t* actions, float* logp,
+                                    uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
+                                    uint64_t step, const uint64_t* step_dev, int64_t env_id0, float* rewards,
+                                    uint8_t* terminated, void* obs, int obs_dtype, uint8_t* legal_mask, uint64_t* packed_obs,
+                                    int32_t* err, float* ep_return, int32_t* ep_length, int64_t* ep_stats, uint32_t flags,
+                                    void* stream);
 
 /* ---- the random-policy rollout of BASELINE.json (RandomPolicy.act -> env.step -> env.reset(done)),
  * T plies per env in one launch with the state held in registers.

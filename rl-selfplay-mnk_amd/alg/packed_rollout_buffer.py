@@ -12,8 +12,12 @@ The caller adds ``wrapper.packed_obs()`` -- taken when the observation was hande
 ``wrapper.step`` that consumes the action -- instead of the dense observation and mask; everything else
 (``add`` order, ``ptr``, "Buffer was full.", ``compute_advantages_and_returns``, ``reset``) is the
 reference's.  With ``wrapper.attach_sink(buffer)`` the step kernel itself writes the packed canonical planes into
-row t+1 (and rewards / terminated into row t): ``add(buffer.row(t)["packed"], ...)`` then copies nothing, and the
-dense observation the network needs for the next forward is the only other thing the step writes.
+row t+1 (and rewards / terminated into row t): ``add`` of a row the step wrote copies nothing, and the dense
+observation the network needs for the next forward is the only other thing the step writes.  The spill-row rule of the
+dense buffer holds here too: the planes that follow the LAST step of a rollout go to the spill row (``row(n_steps)``), so
+the first ``add`` of every later rollout is handed the spill row and copies it into row 0 (32 B per env, once per
+rollout) -- ``add(buffer.row(0)["packed"], ...)`` would store the zeros ``reset()`` left there.  Pass what the step (or
+``wrapper.reset``) returned / ``wrapper.packed_obs()``, as examples/selfplay_ppo.py does.
 """
 import torch
 
@@ -21,7 +25,9 @@ import mnk_hip
 
 
 class PackedRolloutBuffer:
-    def __init__(self, n_steps, num_envs, m, n, device="cuda"):
+    def __init__(self, n_steps, num_envs, m, n, device="cuda", keep_storage=False):
+        self.keep_storage = keep_storage  # reset() zeroes in place instead of allocating (a sink / a graph holds row pointers)
+        self._live = None                 # row of the plane store that holds the observation handed out last (sink only)
         if torch.device(device).type != "cuda":
             raise RuntimeError("PackedRolloutBuffer needs a GPU device (its gather and GAE are HIP kernels)")
         mnk_hip.load()
@@ -35,14 +41,26 @@ class PackedRolloutBuffer:
 
     def reset(self):
         t, n, dev = self.n_steps, self.num_envs, self.device
-        if getattr(self, "planes", None) is not None:  # keep the storage: rows may be bound to the fused step; the spill
-            # row is left alone -- it carries the observation the next rollout starts from
-            for f in (self.planes, self.actions, self.log_probs, self.rewards, self.values, self.returns,
-                      self.advantages, self.dones):
+        if getattr(self, "planes", None) is not None and self.keep_storage:
+            # keep the storage: rows are bound to the fused step.  The spill row(s) and the row that holds the observation
+            # handed out last are left alone -- the next rollout starts from it
+            for f in (self.actions, self.log_probs, self.rewards, self.values, self.returns, self.advantages, self.dones):
                 f.zero_()
+            if self._live is not None and self._live < t:
+                self.planes[:self._live].zero_()
+                self.planes[self._live + 1:].zero_()
+            else:
+                self.planes.zero_()
             self.ptr = 0
             return
-        self._plane_store = torch.zeros((t + 1, 2, self.words, n), dtype=torch.int64, device=dev)  # + the spill row
+        carried = None
+        if getattr(self, "planes", None) is not None and self._live is not None:
+            carried = self._plane_store[self._live].clone()
+        spill = 1 if t >= 2 else 2  # a one-step buffer alternates two spill rows (see RolloutBuffer.reset)
+        self._plane_store = torch.zeros((t + spill, 2, self.words, n), dtype=torch.int64, device=dev)
+        if carried is not None:
+            self._live = t
+            self._plane_store[t].copy_(carried)
         self.planes = self._plane_store[:t]
         self.actions = torch.zeros((t, n), dtype=torch.long, device=dev)
         self.log_probs = torch.zeros((t, n), dtype=torch.float32, device=dev)
@@ -54,8 +72,12 @@ class PackedRolloutBuffer:
         self.ptr = 0
 
     # ------------------------------------------------------------------ the sink of the fused step
+    def sink_attached(self, on: bool) -> None:
+        if on:
+            self.keep_storage = True
+
     def row(self, t: int) -> dict:
-        if not 0 <= t <= self.n_steps:
+        if not 0 <= t < self._plane_store.shape[0]:
             raise IndexError(f"row {t} of a buffer of {self.n_steps} steps")
         out = {"packed": self._plane_store[t]}
         if t < self.n_steps:
@@ -64,13 +86,20 @@ class PackedRolloutBuffer:
         return out
 
     def reset_outputs(self):
-        return {"packed": self._plane_store[self.ptr]} if self.ptr < self.n_steps else None
+        if self.ptr >= self.n_steps:
+            return None
+        self._live = self.ptr
+        return {"packed": self._plane_store[self.ptr]}
 
     def step_outputs(self):
         t = self.ptr
         if t >= self.n_steps:
             return None
-        return {"packed": self._plane_store[t + 1], "rewards": self.rewards[t], "terminated": self.dones[t]}
+        nxt = t + 1
+        if nxt == self.n_steps and self._live == nxt and self._plane_store.shape[0] > nxt + 1:
+            nxt += 1  # a one-step buffer: the other spill row
+        self._live = nxt
+        return {"packed": self._plane_store[nxt], "rewards": self.rewards[t], "terminated": self.dones[t]}
 
     def add(self, packed_obs, action, reward, value, log_prob, done):
         if self.ptr >= self.n_steps:

@@ -11,7 +11,9 @@ The buffer is also the SINK of the fused step: ``w
 ``TorchSelfPlayWrapper.step`` write the next observation / mask into row ``ptr + 1`` and the rewards / terminated flags
 into row ``ptr`` directly (``row(t)``, ``step_outputs()``), and ``add`` skips every field it is handed back as its own
 row -- the reference's loop (alg/ppo.py:93-108) runs unchanged while the 7 ``copy_`` of rollout_buffer.py:47-58 shrink to
-the small per-env vectors.  For that the storage survives ``reset()`` (zeroed in place, not reallocated).
+the small per-env vectors.  While a sink is attached the storage survives ``reset()`` (zeroed in place -- except the row
+that holds the observation handed out last, which the caller is about to act on); without one ``reset()`` allocates fresh
+tensors as the reference does, so views a caller kept (logged batches, a live ``get_data_loader``) keep their data.
 
 This directory has no ``__init__.py`` on purpose: ``alg`` is a namespace package in the reference too, so
 with ``rl-selfplay-mnk_amd/`` ahead of the reference's ``src/`` on ``sys.path`` this module replaces
@@ -37,7 +39,12 @@ def _put(dst: torch.Tensor, src) -> int:
 
 
 class RolloutBuffer:
-    def __init__(self, n_steps, num_envs, obs_shape, action_dim, device="cpu", obs_dtype=torch.float32):
+    def __init__(self, n_steps, num_envs, obs_shape, action_dim, device="cpu", obs_dtype=torch.float32, keep_storage=False):
+        """``keep_storage``: ``reset()`` zeroes the tensors in place instead of allocating fresh ones (the reference
+        allocates, rollout_buffer.py:13-45).  ``wrapper.attach_sink(buffer)`` and ``GraphedRollout`` switch it on: rows
+        handed to the step kernels must stay where they are."""
+        self.keep_storage = keep_storage
+        self._live = None  # row of observations / action_masks that holds the observation handed out last (sink only)
         self.n_steps = n_steps
         self.num_envs = num_envs
         self.obs_shape = obs_shape
@@ -57,12 +64,19 @@ class RolloutBuffer:
 
     def reset(self):
         """reference rollout_buffer.py:13-45: all fields zeroed, write pointer at 0.  The reference allocates fresh
-        tensors every time; here the storage is allocated once and zeroed in place afterwards, so rows handed out to
-        the fused step (``attach_sink``) stay valid across ``PPOAgent.learn`` calls."""
+        tensors every time, and so does this buffer -- unless ``keep_storage`` (a sink is attached / a graph holds row
+        pointers): then the storage is zeroed in place, so rows handed out to the fused step stay valid across
+        ``PPOAgent.learn`` calls.  In-place zeroing spares the row that holds the observation the caller acts on next
+        (the spill row after a full rollout; row 0 right after ``wrapper.reset()``): ``add`` takes it from there."""
         t, n, dev = self.n_steps, self.num_envs, self.device
-        if self.observations is not None:
+        if self.observations is not None and self.keep_storage:
             for name in self._FIELDS:
-                getattr(self, name).zero_()
+                if name in ("observations", "action_masks") and self._live is not None and self._live < t:
+                    store = getattr(self, name)
+                    store[:self._live].zero_()
+                    store[self._live + 1:].zero_()
+                else:
+                    getattr(self, name).zero_()
             self.ptr = 0
             return
 
@@ -71,8 +85,18 @@ class RolloutBuffer:
 
         # one row more than n_steps behind observations / action_masks: the spill row that takes the observation
         # following the last step (PPOAgent._last_obs).  The public fields are views of the first n_steps rows.
-        self._obs_store = field(*self.obs_shape, dtype=self.obs_dtype, rows=t + 1)
-        self._mask_store = field(self.action_dim, dtype=torch.bool, rows=t + 1)
+        # A one-step buffer gets TWO spill rows, used in turn: there the step that acts on the carried-over observation
+        # is also the last step, and its next observation must not land on the row `add` is still to read.
+        spill = 1 if t >= 2 else 2
+        carried = None
+        if self.observations is not None and self._live is not None:  # a sink was detached: carry the live observation over
+            carried = (self._obs_store[self._live].clone(), self._mask_store[self._live].clone())
+        self._obs_store = field(*self.obs_shape, dtype=self.obs_dtype, rows=t + spill)
+        self._mask_store = field(self.action_dim, dtype=torch.bool, rows=t + spill)
+        if carried is not None:
+            self._live = t
+            self._obs_store[t].copy_(carried[0])
+            self._mask_store[t].copy_(carried[1])
         self.observations = self._obs_store[:t]
         self.actions = field(dtype=torch.long)
         self.log_probs = field()
@@ -85,10 +109,15 @@ class RolloutBuffer:
         self.ptr = 0
 
     # ------------------------------------------------------------------ the sink of the fused step
+    def sink_attached(self, on: bool) -> None:
+        """called by ``TorchSelfPlayWrapper.attach_sink``: from now on the step kernels hold row pointers of this buffer"""
+        if on:
+            self.keep_storage = True
+
     def row(self, t: int) -> dict:
         """Views of row ``t`` of every per-step field (``t == n_steps``: the spill row, observation and mask only): what
-        ``TorchSelfPlayWrapper.step(actions, out=...)`` and ``mnk_sample_logits`` can write in place."""
-        if not 0 <= t <= self.n_steps:
+        ``TorchSelfPlayWrapper.step(actions, out=...)`` and the step kernels' folded-in draw can write in place."""
+        if not 0 <= t < self._obs_store.shape[0]:
             raise IndexError(f"row {t} of a buffer of {self.n_steps} steps")
         out = {"observation": self._obs_store[t], "action_mask": self._mask_store[t]}
         if t < self.n_steps:
@@ -100,8 +129,17 @@ class RolloutBuffer:
         """where ``wrapper.reset()`` puts the first observation: the row the next ``add`` fills"""
         if self.ptr >= self.n_steps:
             return None
+        self._live = self.ptr
         r = self.row(self.ptr)
         return {"observation": r["observation"], "action_mask": r["action_mask"]}
+
+    def _next_row(self, t: int) -> int:
+        """the row that takes the observation following step t: t + 1, the spill row after the last step -- of a
+        one-step buffer's two spill rows the one that does not hold the observation being acted on"""
+        nxt = t + 1
+        if nxt == self.n_steps and self._live == nxt and self._obs_store.shape[0] > nxt + 1:
+            nxt += 1
+        return nxt
 
     def step_outputs(self):
         """where ``wrapper.step()`` puts its outputs while the write pointer stands at row t: next observation / mask
@@ -109,7 +147,8 @@ class RolloutBuffer:
         t = self.ptr
         if t >= self.n_steps:
             return None
-        nxt = self.row(t + 1)
+        self._live = self._next_row(t)
+        nxt = self.row(self._live)
         return {"observation": nxt["observation"], "action_mask": nxt["action_mask"], "rewards": self.rewards[t],
                 "terminated": self.dones[t]}
 

@@ -60,7 +60,7 @@ inline int mnk_launch_status(const char* what) {
   return MNK_ELAUNCH;
 }
 
-inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+__host__ __device__ inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 // Developer knobs from the environment (A/B timing, parity tests of every kernel form), read ONCE -- a launch used to
 // cost four or five getenv() calls, which is nothing beside a 90 us rollout launch but not beside a 5 us step.
@@ -116,9 +116,13 @@ inline int mnk_block_envs(int64_t items) {
 // 256 when an observation is written (1.3-1.7x faster than 64, tools/exp_emit.py); 128 when only the legal mask leaves
 // (an eighth of the bytes: two waves sweep it as fast as four and start sooner -- mnk_step_random at 65 536 envs 4.77 ->
 // 4.68 us per ply, at 262 144 envs 11.0 -> 9.5, tools/exp_one_launch.py)
+// Never fewer threads than envs per workgroup: lane tid plays env env0 + tid, so with MNK_EMIT_ENVS=128 a 64-thread
+// workgroup would leave envs 64..127 of every workgroup unplayed and emit them from an unfilled stage.
 inline int mnk_block_threads(bool writes_obs = true) {
-  if (const int forced = mnk_config().emit_threads) return forced;
-  return writes_obs ? 256 : 128;
+  const int envs = mnk_config().emit_envs;  // 0 unless forced; the default 32 / 64 never exceeds the defaults below
+  int threads = writes_obs ? 256 : 128;
+  if (const int forced = mnk_config().emit_threads) threads = forced;
+  return threads < envs ? envs : threads;
 }
 
 // Kernel variants: NW = u32 register words per plane; CN / CK = compile-time board width and
@@ -171,6 +175,24 @@ inline bool mnk_act_format_ok(int act, int C) {
   return act == 0 || act == MNK_ACT_U16 || (act == MNK_ACT_U8 && C <= 256) || (act == MNK_ACT_BITS7 && C <= 128) ||
          (act == MNK_ACT_U8P1 && C > 256);  // (U8P1 would hold any board; only the boards that need it have kernel variants)
 }
+
+// A masked draw from a policy head's logits (mnk_sample_logits; the mnk_selfplay_*_logits entry points fold it into a
+// step kernel): where the logits and the mask live, the sampler's Philox key and position, where the results go.
+struct MnkSample {
+  const void* logits;        // [N][C] f32 / bf16 bit patterns; NULL = all-zero logits (uniform over the mask)
+  int logits_dtype;          // MNK_LOGITS_F32 / MNK_LOGITS_BF16
+  const uint8_t* mask;       // [N][C]
+  uint64_t seed;
+  const uint64_t* seed_dev;  // optional device word that REPLACES seed (a captured graph's sampler can be re-keyed)
+  uint64_t step;
+  const uint64_t* step_dev;  // optional device word ADDED to step
+  int64_t env_id0;           // Philox row id of row 0
+  int deterministic;
+  int64_t* actions;          // out [N]
+  float* logp;               // out [N], optional
+};
+// the draw as a launch of its own (mnk_sample.hip)
+int mnk_launch_sample(const MnkSample& sa, int64_t N, int C, hipStream_t s);
 
 // one-lane rollout variants that write the action log (mnk_rollout_log.hip); act_bytes is 1 or 2
 void mnk_launch_rollout_log(const MnkGeom& g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed,

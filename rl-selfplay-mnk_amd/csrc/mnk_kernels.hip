@@ -8,6 +8,7 @@
 // B consecutive envs, and the same env -> workgroup map in every kernel so an env's
 // state stays in the L2 of the XCD that touched it last.
 #include "mnk_host.h"
+#include "mnk_selfplay_kernels.h"
 
 // ------------------------------------------------------------------ reset
 __global__ void k_reset_idx(uint64_t* planes, uint32_t* meta, int64_t N, int W, const int64_t* idx, int64_t R,
@@ -99,14 +100,6 @@ k_step_subset(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int6
 }
 
 // ------------------------------------------------------------------ observe / unpack
-// the view (channel 0, channel 1) of env i as packed planes u64[2][W][N]: what PackedRolloutBuffer stores
-template <int NW>
-__device__ __forceinline__ void mnk_packed_put(uint64_t* packed, int64_t N, int W, int64_t i, const uint32_t (&ch0)[NW],
-                                               const uint32_t (&ch1)[NW]) {
-  plane_store<NW>(ch0, packed, N, W, i);
-  plane_store<NW>(ch1, packed + (int64_t)W * N, N, W, i);
-}
-
 template <int NW, int CN, int CK>
 __global__ void __launch_bounds__(256)
 k_observe(MnkGeom g, const uint64_t* planes, int64_t N, const int64_t* flip_side, void* obs, int obs_dtype,
@@ -170,224 +163,6 @@ k_sample_legal(MnkGeom g, const uint64_t* planes, int64_t N, uint64_t seed, uint
   e.meta = 0u;
   const uint32_t x = mnk_rand_u32(seed, (uint64_t)(env_id0 + i), step, stream_id);
   actions[i] = env_pick_legal<NW, CN>(g, e, x);
-}
-
-// ------------------------------------------------------------------ fused self-play step
-// selfplay/torch_self_play_wrapper.py:32-67 as fixed-shape masked kernels.  The reference
-// builds nonzero() index lists (two host syncs each) for "envs to reset", "envs to play" and
-// "envs where the opponent replies"; here every env carries those three facts as bits.
-// Optional device-side episode accounting: what alg/ppo.py:110-120 does
-// on the host with dones.any() + nonzero + tolist (two synchronisations per step).  Per env the running
-// return and length (in agent-steps, the autoreset step included, as ppo.py:110-111 counts them); on
-// termination the episode is classified by its return and folded into replicated counters.
-struct MnkEpisodes {
-  float* ep_return;            // [N]
-  int32_t* ep_length;          // [N]
-  unsigned long long* stats;   // [MNK_STATS_REPLICAS][MNK_STATS_STRIDE]: episodes, wins, losses, draws, sum of lengths
-};
-
-__device__ __forceinline__ void mnk_ep_account(const MnkEpisodes& ep, int64_t i, float rew, bool term,
-                                               unsigned int* lds5) {
-  float ret = ep.ep_return[i] + rew;
-  int len = ep.ep_length[i] + 1;
-  if (term) {
-    atomicAdd(&lds5[0], 1u);
-    atomicAdd(&lds5[ret > 0.0f ? 1 : (ret < 0.0f ? 2 : 3)], 1u);
-    atomicAdd(&lds5[4], (unsigned int)len);
-    ret = 0.0f;
-    len = 0;
-  }
-  ep.ep_return[i] = ret;
-  ep.ep_length[i] = len;
-}
-
-__device__ __forceinline__ void mnk_ep_flush(const MnkEpisodes& ep, const unsigned int* lds5) {
-  if (threadIdx.x < MNK_STATS_COUNTERS && lds5[threadIdx.x])
-    atomicAdd(&ep.stats[(size_t)(blockIdx.x % MNK_STATS_REPLICAS) * MNK_STATS_STRIDE + threadIdx.x],
-              (unsigned long long)lds5[threadIdx.x]);
-}
-
-struct SpAgent {
-  float reward;
-  bool term, was_reset, need_opp;
-};
-
-// wrapper:39-63 up to (not including) the opponent's reply, for one env
-template <int NW, int CN, int CK>
-__device__ __forceinline__ SpAgent sp_agent_half(const MnkGeom& g, MnkEnv<NW>& e, int64_t action, bool pending,
-                                                 int64_t& side, const int64_t* forced_side, uint64_t seed,
-                                                 uint64_t step, uint64_t env, int64_t i, int32_t* err, bool strict) {
-  SpAgent a;
-  a.reward = 0.0f; a.term = false; a.was_reset = pending;
-  if (pending) {
-    env_clear<NW>(e);  // wrapper:41 env.reset(reset_idxs)
-    side = forced_side ? (forced_side[i] & 1) : (int64_t)(mnk_rand_u32(seed, env, step, MNK_STREAM_SIDE) >> 31);  // :43-45
-  } else {
-    const MnkPly ply = env_play<NW, CN, CK>(g, e, action, strict);  // :51
-    if (ply.err) mnk_report(err, ply.err, i);
-    a.reward = ply.win ? 1.0f : 0.0f;  // :53
-    a.term = ply.done;                 // :54
-  }
-  // :46 / :56-59 -> _opponent_move_if_needed: reply where it is not the agent's turn (:74-77)
-  a.need_opp = (a.was_reset || !a.term) && ((int64_t)(e.meta & 1u) != side);
-  return a;
-}
-
-template <int NW, int CN, int CK>
-__global__ void __launch_bounds__(256)
-k_selfplay_pre(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions,
-               const uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
-               uint64_t step, const uint64_t* step_dev, int64_t env_id0, float* rewards, uint8_t* terminated,
-               uint8_t* sp_flags, void* opp_obs, int obs_dtype, uint8_t* opp_mask, int32_t* err, uint32_t flags,
-               int vec_ok, int envs_per_block) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  if (step_dev) step += *step_dev;
-  const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
-  const int64_t env0 = (int64_t)blockIdx.x * B;
-  const int64_t i = env0 + tid;
-  const bool emit = opp_obs || opp_mask;
-  MnkStage st = mnk_stage_carve(lds_raw, g, B);
-  if (emit) mnk_stage_tables(st, g, B, tid, NT);
-  if (tid < B && i < N) {
-    MnkEnv<NW> e;
-    env_load<NW>(e, planes, meta, N, g.W, i);
-    int64_t side = agent_side[i];
-    const bool pend = pending[i] != 0;
-    const SpAgent a = sp_agent_half<NW, CN, CK>(g, e, actions[i], pend, side, forced_side, seed, step,
-                                        (uint64_t)(env_id0 + i), i, err, (flags & MNK_STEP_STRICT) != 0);
-    env_store<NW>(e, planes, meta, N, g.W, i);
-    if (pend) agent_side[i] = side;
-    rewards[i] = a.reward;
-    terminated[i] = a.term ? 1 : 0;
-    sp_flags[i] = (a.need_opp ? MNK_SP_NEED_OPP : 0u) | (a.was_reset ? MNK_SP_WAS_RESET : 0u);
-    if (emit) {
-      // wrapper:83-89: the mover sees itself in channel 0
-      const bool white_to_move = (e.meta & 1u) != 0;
-      if (white_to_move) mnk_stage_put<NW>(st, g, B, tid, e.p[1], e.p[0], !a.need_opp);
-      else mnk_stage_put<NW>(st, g, B, tid, e.p[0], e.p[1], !a.need_opp);
-    }
-  }
-  if (emit) {
-    const int64_t left = N - env0;
-    const int nb = left < B ? (int)left : B;
-    mnk_write_out<NW, CN, CK>(st, g, B, nb, mnk_obs_slab(opp_obs, obs_dtype, env0, g.C), obs_dtype,
-                              opp_mask ? opp_mask + env0 * g.C : nullptr, vec_ok, tid, NT);
-  }
-}
-
-template <int NW, int CN, int CK>
-__global__ void __launch_bounds__(256)
-k_selfplay_post(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* opp_actions,
-                const uint8_t* sp_flags, const int64_t* agent_side, float* rewards, uint8_t* terminated,
-                uint8_t* pending, void* obs, int obs_dtype, uint8_t* legal_mask, uint64_t* packed_obs, int32_t* err,
-                MnkEpisodes ep, uint32_t flags, int vec_ok, int envs_per_block) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  __shared__ unsigned int lds_ep[MNK_STATS_COUNTERS];
-  const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
-  const int64_t env0 = (int64_t)blockIdx.x * B;
-  const int64_t i = env0 + tid;
-  const bool emit = obs || legal_mask;
-  MnkStage st = mnk_stage_carve(lds_raw, g, B);
-  if (emit) mnk_stage_tables(st, g, B, tid, NT);
-  if (ep.stats) {
-    if (tid < MNK_STATS_COUNTERS) lds_ep[tid] = 0u;
-    __syncthreads();
-  }
-  if (tid < B && i < N) {
-    MnkEnv<NW> e;
-    env_load<NW>(e, planes, meta, N, g.W, i);
-    const uint32_t f = sp_flags[i];
-    float rew = rewards[i];
-    bool term = terminated[i] != 0;
-    if (f & MNK_SP_NEED_OPP) {
-      const MnkPly ply = env_play<NW, CN, CK>(g, e, opp_actions[i], (flags & MNK_STEP_STRICT) != 0);  // wrapper:96
-      if (ply.err) mnk_report(err, ply.err, i);
-      else env_store<NW>(e, planes, meta, N, g.W, i);
-      if (!(f & MNK_SP_WAS_RESET)) {  // :46 ignores the reply's outcome after a reset
-        rew -= ply.win ? 1.0f : 0.0f;  // :62
-        term = ply.done;               // :63
-      }
-      rewards[i] = rew;
-      terminated[i] = term ? 1 : 0;
-    }
-    pending[i] = term ? 1 : 0;  // :65
-    if (ep.stats) mnk_ep_account(ep, i, rew, term, lds_ep);
-    const bool white = agent_side[i] == 1;  // :104-106
-    if (emit) {
-      if (white) mnk_stage_put<NW>(st, g, B, tid, e.p[1], e.p[0], true);
-      else mnk_stage_put<NW>(st, g, B, tid, e.p[0], e.p[1], true);
-    }
-    if (packed_obs) mnk_packed_put<NW>(packed_obs, N, g.W, i, white ? e.p[1] : e.p[0], white ? e.p[0] : e.p[1]);
-  }
-  if (emit) {  // (synchronises: the episode counters in LDS are complete after it, too)
-    const int64_t left = N - env0;
-    const int nb = left < B ? (int)left : B;
-    mnk_write_out<NW, CN, CK>(st, g, B, nb, mnk_obs_slab(obs, obs_dtype, env0, g.C), obs_dtype,
-                              legal_mask ? legal_mask + env0 * g.C : nullptr, vec_ok, tid, NT);
-  } else if (ep.stats) {
-    __syncthreads();
-  }
-  if (ep.stats) mnk_ep_flush(ep, lds_ep);
-}
-
-// the whole wrapper.step in one launch when the opponent is RandomPolicy (policy.py:13-29)
-template <int NW, int CN, int CK>
-__global__ void __launch_bounds__(256)
-k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions,
-                       uint8_t* pending, int64_t* agent_side, const int64_t* forced_side, uint64_t seed,
-                       uint64_t step, const uint64_t* step_dev, int64_t env_id0, float* rewards,
-                       uint8_t* terminated, void* obs, int obs_dtype, uint8_t* legal_mask, uint64_t* packed_obs,
-                       int32_t* err, MnkEpisodes ep, uint32_t flags, int vec_ok, int envs_per_block) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  if (step_dev) step += *step_dev;
-  __shared__ unsigned int lds_ep[MNK_STATS_COUNTERS];
-  const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
-  const int64_t env0 = (int64_t)blockIdx.x * B;
-  const int64_t i = env0 + tid;
-  const bool emit = obs || legal_mask;
-  MnkStage st = mnk_stage_carve(lds_raw, g, B);
-  if (emit) mnk_stage_tables(st, g, B, tid, NT);
-  if (ep.stats) {
-    if (tid < MNK_STATS_COUNTERS) lds_ep[tid] = 0u;
-    __syncthreads();
-  }
-  if (tid < B && i < N) {
-    MnkEnv<NW> e;
-    env_load<NW>(e, planes, meta, N, g.W, i);
-    int64_t side = agent_side[i];
-    const bool pend = pending[i] != 0;
-    const uint64_t env = (uint64_t)(env_id0 + i);
-    SpAgent a = sp_agent_half<NW, CN, CK>(g, e, actions[i], pend, side, forced_side, seed, step, env, i, err,
-                                          (flags & MNK_STEP_STRICT) != 0);
-    if (a.need_opp) {
-      const int oa = env_pick_legal<NW, CN>(g, e, mnk_rand_u32(seed, env, step, MNK_STREAM_OPP));
-      const MnkPly ply = env_play<NW, CN, CK, true>(g, e, oa, false);
-      if (!a.was_reset) {
-        a.reward -= ply.win ? 1.0f : 0.0f;
-        a.term = ply.done;
-      }
-    }
-    env_store<NW>(e, planes, meta, N, g.W, i);
-    if (pend) agent_side[i] = side;
-    rewards[i] = a.reward;
-    terminated[i] = a.term ? 1 : 0;
-    pending[i] = a.term ? 1 : 0;
-    if (ep.stats) mnk_ep_account(ep, i, a.reward, a.term, lds_ep);
-    if (emit) {
-      if (side == 1) mnk_stage_put<NW>(st, g, B, tid, e.p[1], e.p[0], true);
-      else mnk_stage_put<NW>(st, g, B, tid, e.p[0], e.p[1], true);
-    }
-    if (packed_obs) mnk_packed_put<NW>(packed_obs, N, g.W, i, side == 1 ? e.p[1] : e.p[0], side == 1 ? e.p[0] : e.p[1]);
-  }
-  if (emit) {  // (synchronises: the episode counters in LDS are complete after it, too)
-    const int64_t left = N - env0;
-    const int nb = left < B ? (int)left : B;
-    mnk_write_out<NW, CN, CK>(st, g, B, nb, mnk_obs_slab(obs, obs_dtype, env0, g.C), obs_dtype,
-                              legal_mask ? legal_mask + env0 * g.C : nullptr, vec_ok, tid, NT);
-  } else if (ep.stats) {
-    __syncthreads();
-  }
-  if (ep.stats) mnk_ep_flush(ep, lds_ep);
 }
 
 // ------------------------------------------------------------------ records -> RolloutBuffer layout
@@ -727,21 +502,13 @@ int mnk_selfplay_pre(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, 
                      uint64_t step, const uint64_t* step_dev, int64_t env_id0, float* rewards, uint8_t* terminated,
                      uint8_t* sp_flags, void* opp_obs, int obs_dtype, uint8_t* opp_mask, int32_t* err, uint32_t flags,
                      void* stream) {
-  MnkGeom g;
-  int rc = mnk_check_geom(m, n, k, &g);
+  MnkSpArgs a;
+  int rc = mnk_sp_args_pre(&a, planes, meta, N, m, n, k, pending, agent_side, forced_side, seed, step, step_dev, env_id0,
+                           rewards, terminated, sp_flags, opp_obs, obs_dtype, opp_mask, err, flags);
   if (rc != MNK_OK) return rc;
-  if (!planes || !meta || !actions || !pending || !agent_side || !rewards || !terminated || !sp_flags || N < 0 ||
-      !mnk_obs_dtype_ok(obs_dtype))
-    return MNK_EINVAL;
+  if (!actions) return MNK_EINVAL;
   if (N == 0) return MNK_OK;
-  const int B = mnk_block_envs(N);
-  const bool emit = opp_obs || opp_mask;
-  const int vec_ok = (aligned16(opp_obs) ? 1 : 0) | (aligned16(opp_mask) ? 2 : 0);
-  const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, g.k) : 0;
-  const dim3 grid((unsigned)((N + B - 1) / B));
-  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_pre), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, planes, meta,
-                                         N, actions, pending, agent_side, forced_side, seed, step, step_dev, env_id0,
-                                         rewards, terminated, sp_flags, opp_obs, obs_dtype, opp_mask, err, flags, vec_ok, B));
+  MNK_DISPATCH(a.g, mnk_launch_sp<MNK_SP_PRE, NW, CN, CK, NoDraw>(a, actions, MnkSample{}, (hipStream_t)stream));
   return mnk_launch_status("selfplay_pre");
 }
 
@@ -749,23 +516,13 @@ int mnk_selfplay_post(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n,
                       const uint8_t* sp_flags, const int64_t* agent_side, float* rewards, uint8_t* terminated,
                       uint8_t* pending, void* obs, int obs_dtype, uint8_t* legal_mask, uint64_t* packed_obs, int32_t* err,
                       float* ep_return, int32_t* ep_length, int64_t* ep_stats, uint32_t flags, void* stream) {
-  MnkGeom g;
-  int rc = mnk_check_geom(m, n, k, &g);
+  MnkSpArgs a;
+  int rc = mnk_sp_args_post(&a, planes, meta, N, m, n, k, sp_flags, agent_side, rewards, terminated, pending, obs, obs_dtype,
+                            legal_mask, packed_obs, err, ep_return, ep_length, ep_stats, flags);
   if (rc != MNK_OK) return rc;
-  if (!planes || !meta || !opp_actions || !sp_flags || !agent_side || !rewards || !terminated || !pending || N < 0 ||
-      !mnk_obs_dtype_ok(obs_dtype))
-    return MNK_EINVAL;
-  if (ep_stats && (!ep_return || !ep_length)) return MNK_EINVAL;
-  const MnkEpisodes ep = {ep_return, ep_length, (unsigned long long*)ep_stats};
+  if (!opp_actions) return MNK_EINVAL;
   if (N == 0) return MNK_OK;
-  const int B = mnk_block_envs(N);
-  const bool emit = obs || legal_mask;
-  const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
-  const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, g.k) : 0;
-  const dim3 grid((unsigned)((N + B - 1) / B));
-  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_post), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, planes,
-                                         meta, N, opp_actions, sp_flags, agent_side, rewards, terminated, pending, obs,
-                                         obs_dtype, legal_mask, packed_obs, err, ep, flags, vec_ok, B));
+  MNK_DISPATCH(a.g, mnk_launch_sp<MNK_SP_POST, NW, CN, CK, NoDraw>(a, opp_actions, MnkSample{}, (hipStream_t)stream));
   return mnk_launch_status("selfplay_post");
 }
 
@@ -775,24 +532,14 @@ int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m,
                              uint8_t* terminated, void* obs, int obs_dtype, uint8_t* legal_mask, uint64_t* packed_obs,
                              int32_t* err, float* ep_return, int32_t* ep_length, int64_t* ep_stats, uint32_t flags,
                              void* stream) {
-  MnkGeom g;
-  int rc = mnk_check_geom(m, n, k, &g);
+  MnkSpArgs a;
+  int rc = mnk_sp_args_step_random(&a, planes, meta, N, m, n, k, pending, agent_side, forced_side, seed, step, step_dev,
+                                   env_id0, rewards, terminated, obs, obs_dtype, legal_mask, packed_obs, err, ep_return,
+                                   ep_length, ep_stats, flags);
   if (rc != MNK_OK) return rc;
-  if (!planes || !meta || !actions || !pending || !agent_side || !rewards || !terminated || N < 0 ||
-      !mnk_obs_dtype_ok(obs_dtype))
-    return MNK_EINVAL;
-  if (ep_stats && (!ep_return || !ep_length)) return MNK_EINVAL;
-  const MnkEpisodes ep = {ep_return, ep_length, (unsigned long long*)ep_stats};
+  if (!actions) return MNK_EINVAL;
   if (N == 0) return MNK_OK;
-  const int B = mnk_block_envs(N);
-  const bool emit = obs || legal_mask;
-  const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
-  const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, g.k) : 0;
-  const dim3 grid((unsigned)((N + B - 1) / B));
-  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_selfplay_step_random), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g,
-                                         planes, meta, N, actions, pending, agent_side, forced_side, seed, step,
-                                         step_dev, env_id0, rewards, terminated, obs, obs_dtype, legal_mask, packed_obs, err,
-                                         ep, flags, vec_ok, B));
+  MNK_DISPATCH(a.g, mnk_launch_sp<MNK_SP_STEP_RANDOM, NW, CN, CK, NoDraw>(a, actions, MnkSample{}, (hipStream_t)stream));
   return mnk_launch_status("selfplay_step_random");
 }
 

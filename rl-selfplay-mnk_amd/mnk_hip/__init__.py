@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MNK_HIP_LIB: another build of the same library (A/B experiments with compile-time options); default: the in-tree build
 LIB_PATH = os.environ.get("MNK_HIP_LIB") or os.path.join(_HERE, "libmnk_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 MNK_OK = 0
 ERR_NONE, ERR_ACTION_RANGE, ERR_ILLEGAL_MOVE = 0, 1, 2
@@ -47,13 +47,22 @@ SIGNATURES = {
     "mnk_pack_boards": [_vp, _vp, _i64, _i, _i, _vp],
     "mnk_unpack_boards": [_vp, _vp, _i64, _i, _i, _vp],
     "mnk_sample_legal": [_vp, _i64, _i, _i, _u64, _u64, _vp, _i64, _i, _vp, _vp],
-    "mnk_sample_logits": [_vp, _i, _vp, _i64, _i, _u64, _u64, _vp, _i64, _i, _vp, _vp, _vp],
+    "mnk_sample_logits": [_vp, _i, _vp, _i64, _i, _u64, _vp, _u64, _vp, _i64, _i, _vp, _vp, _vp],
     "mnk_selfplay_pre": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _vp, _vp, _vp,
                          _i, _vp, _vp, _u32, _vp],
     "mnk_selfplay_post": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp,
                           _vp, _u32, _vp],
     "mnk_selfplay_step_random": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _vp,
                                  _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    # the sampler block of the *_logits forms: logits, dtype, mask, seed, seed_dev, step, step_dev, env_id0, deterministic,
+    # actions (out), logp (out)
+    "mnk_selfplay_pre_logits": [_vp, _vp, _i64, _i, _i, _i] + [_vp, _i, _vp, _u64, _vp, _u64, _vp, _i64, _i, _vp, _vp] +
+                               [_vp, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _u32, _vp],
+    "mnk_selfplay_post_logits": [_vp, _vp, _i64, _i, _i, _i] + [_vp, _i, _vp, _u64, _vp, _u64, _vp, _i64, _i, _vp, _vp] +
+                                [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    "mnk_selfplay_step_random_logits": [_vp, _vp, _i64, _i, _i, _i] + [_vp, _i, _vp, _u64, _vp, _u64, _vp, _i64, _i, _vp, _vp] +
+                                       [_vp, _vp, _vp, _u64, _u64, _vp, _i64, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                        _u32, _vp],
     "mnk_rollout_random": [_vp, _vp, _i64, _i, _i, _i, _i, _u64, _u64, _i64, _vp, _vp, _vp, _vp, _i, _vp],
     "mnk_action_log_words": [_i, _i],
     "mnk_replay_actions": [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp],

@@ -16,7 +16,10 @@ those facts as bits and one step is
     mnk_selfplay_post  opponent ply, zero-sum merge, agent's canonical view (1 launch)
 
 with no host synchronisation; with the built-in ``RandomPolicy`` as opponent the
-three collapse into the single launch ``mnk_selfplay_step_random``.
+three collapse into the single launch ``mnk_selfplay_step_random``.  The masked draws fold into these kernels too
+(SURVEY.md section 7 step 5): a ``FusedNNPolicy`` opponent only runs its network, its mask + softmax + draw happen inside
+``mnk_selfplay_post_logits``; ``step_logits`` does the same for the agent (``mnk_selfplay_pre_logits`` /
+``mnk_selfplay_step_random_logits``) -- a network-vs-network agent-step is 2 env-side launches, not 4.
 
 Every output of a step is caller-ownable: ``step(actions, out={...})`` writes the next observation, mask, rewards and
 terminated flags straight into the tensors it is given, and ``attach_sink(buffer)`` makes the wrapper take them from
@@ -62,6 +65,8 @@ class TorchSelfPlayWrapper:
         self._ep_return = self._ep_length = self._ep_stats = None  # see track_episodes()
         self.step_dev = None  # optional device int64[1] added to step_count inside the kernels (graph replays)
         self._sink = None     # see attach_sink()
+        self.fuse_opponent_draw = True  # a FusedNNPolicy opponent's draw runs inside mnk_selfplay_post_logits (False: as a
+        self.last_opponent_actions = None  # launch of its own before mnk_selfplay_post -- same results, for A/B timing)
         self._truncated = torch.zeros(self.num_envs, dtype=torch.bool, device=self._dev)  # wrapper:66: always all-False
 
     def set_opponent(self, policy):  # reference wrapper:16-17
@@ -94,7 +99,9 @@ class TorchSelfPlayWrapper:
         and the 7 ``copy_`` per step of alg/rollout_buffer.py:47-58 move ~1 MB instead of ~100 MB at 65 536 envs.  The
         observation that follows the buffer's last row goes to a spill row of the buffer (``PPOAgent._last_obs`` across
         ``learn`` calls); the buffer must keep its storage across ``reset()`` (the drop-in buffers do).
-        ``attach_sink(None)`` detaches."""
+        ``attach_sink(None)`` detaches.  One-step buffers work too (they keep two spill rows and use them in turn)."""
+        if sink is not None and hasattr(sink, "sink_attached"):
+            sink.sink_attached(True)  # its reset() must zero in place from now on: the step kernels hold its row pointers
         self._sink = sink
 
     def _sink_outputs(self, is_reset: bool):
@@ -131,9 +138,12 @@ class TorchSelfPlayWrapper:
     # ------------------------------------------------------------------ checkpoint / resume
     def state_dict(self) -> dict:
         """Env state + sides, pending resets, Philox key and step counter (+ episode accounting when tracked): a
-        wrapper restored from it continues exactly where this one stands."""
+        wrapper restored from it continues exactly where this one stands.  ``step_count`` is the EFFECTIVE Philox step:
+        under a captured graph (``selfplay.graphed``) the advancing part lives in the device counter ``step_dev`` and is
+        added here, so a checkpoint taken after graphed rollouts does not replay their side / opponent draws."""
+        step = self.step_count + (int(self.step_dev.item()) if self.step_dev is not None else 0)
         out = {"env": self.env.state_dict(), "agent_side": self.agent_side.cpu(), "pending_resets": self.pending_resets.cpu(),
-               "seed": self.seed, "step_count": self.step_count, "env_id0": self.env_id0}
+               "seed": self.seed, "step_count": step, "env_id0": self.env_id0}
         if self._ep_stats is not None:
             out["episodes"] = (self._ep_return.cpu(), self._ep_length.cpu(), self._ep_stats.cpu())
         return out
@@ -142,7 +152,12 @@ class TorchSelfPlayWrapper:
         self.env.load_state_dict(state["env"])
         self.agent_side.copy_(state["agent_side"])
         self.pending_resets.copy_(state["pending_resets"])
-        self.seed, self.step_count, self.env_id0 = int(state["seed"]), int(state["step_count"]), int(state["env_id0"])
+        self.seed, self.env_id0 = int(state["seed"]), int(state["env_id0"])
+        if self.step_dev is not None:
+            # captured: the kernels compute step_count (baked into the graph's nodes) + *step_dev -- move the device part
+            self.step_dev.fill_(int(state["step_count"]) - self.step_count)
+        else:
+            self.step_count = int(state["step_count"])
         if "episodes" in state:
             self.track_episodes()
             for dst, src in zip((self._ep_return, self._ep_length, self._ep_stats), state["episodes"]):
@@ -212,7 +227,38 @@ class TorchSelfPlayWrapper:
                              f"{tuple(t.shape)} (contiguous: {t.is_contiguous()}) on {t.device}")
         return t
 
-    def _advance(self, actions, forced, out=None):
+    def step_logits(self, logits, action_mask, sampler, deterministic: bool = False, out=None, actions_out=None,
+                    logp_out=None):
+        """``step`` with the agent's masked draw folded into the step kernel: instead of actions the step takes the RAW
+        logits of the agent's policy head on the current observation (f32 / bf16 ``[N, C]``; ``None`` = the uniformly
+        random agent), the mask that observation came with, and a ``selfplay.policy.HipSampler`` (e.g. a
+        ``FusedNNPolicy``'s ``_sampler``), and does what ``FusedNNPolicy.act`` + ``step`` do -- mask, softmax, draw
+        (policy.py:46-52 over cnn.py:69-79), log-probability (ppo.py:96-97), then wrapper:32-67 -- with one launch
+        fewer.  Same random stream: bit-identical to ``sampler.draw(logits, mask, ..., want_logp=True)`` followed by
+        ``step(actions)``.  Returns ``(obs, rewards, terminated, truncated, {"actions": ..., "log_probs": ...})``;
+        ``actions_out`` int64 ``[N]`` / ``logp_out`` float32 ``[N]``: caller-owned tensors for the two (rows of a
+        rollout buffer)."""
+        from selfplay.policy import HipSampler
+
+        logits, dtype, mask = HipSampler.prepare(logits, action_mask)
+        n = self.num_envs
+        if mask.shape != (n, self.env.max_moves):
+            raise IndexError(f"shape mismatch: mask {tuple(mask.shape)} for {n} envs of {self.env.max_moves} cells")
+        acts = actions_out if actions_out is not None else torch.empty(n, dtype=torch.long, device=self._dev)
+        logp = logp_out if logp_out is not None else torch.empty(n, dtype=torch.float32, device=self._dev)
+        if acts.dtype != torch.long or logp.dtype != torch.float32 or acts.shape != (n,) or logp.shape != (n,):
+            raise TypeError("actions_out must be int64 [N], logp_out float32 [N]")
+        draw = (mnk_hip.ptr(logits), dtype, mnk_hip.ptr(mask)) + sampler.block(deterministic) + (mnk_hip.ptr(acts), mnk_hip.ptr(logp))
+        keep = (logits, mask)  # alive until the launch is enqueued
+        obs, rew, term, trunc, _ = self._advance(None, self._forced_sides, out if out is not None else self._sink_outputs(False),
+                                                 agent_draw=draw)
+        del keep
+        sampler.advance()
+        return obs, rew, term, trunc, {"actions": acts, "log_probs": logp}
+
+    def _advance(self, actions, forced, out=None, agent_draw=None):
+        """One reset / step.  ``agent_draw``: the sampler block of ``mnk_selfplay_*_logits`` (logits, dtype, mask, seed,
+        seed_dev, step, step_dev, env_id0, deterministic, actions out, logp out) instead of ``actions``."""
         env = self.env
         n = self.num_envs
         dev = self._dev
@@ -231,39 +277,57 @@ class TorchSelfPlayWrapper:
         if n == 0:
             return {"observation": obs, "action_mask": mask}, rewards, terminated, self._truncated, {}
 
+        geo = (mnk_hip.ptr(env._planes), mnk_hip.ptr(env._meta), n, env.m, env.n, env.k)
         if getattr(opp, "fused_uniform_random", False):
-            # RandomPolicy opponent: the whole step is one launch
-            mnk_hip.call("mnk_selfplay_step_random", mnk_hip.ptr(env._planes), mnk_hip.ptr(env._meta), n, env.m,
-                         env.n, env.k, mnk_hip.ptr(actions), mnk_hip.ptr(self.pending_resets),
-                         mnk_hip.ptr(self.agent_side), mnk_hip.ptr(forced), self.seed, step,
-                         mnk_hip.ptr(self.step_dev), self.env_id0,
-                         mnk_hip.ptr(rewards), mnk_hip.ptr(terminated), mnk_hip.ptr(obs), mnk_hip.obs_code(obs),
-                         mnk_hip.ptr(mask), mnk_hip.ptr(packed),
-                         mnk_hip.ptr(env._err), mnk_hip.ptr(self._ep_return), mnk_hip.ptr(self._ep_length),
-                         mnk_hip.ptr(self._ep_stats), env._flags(), env._stream())
+            # RandomPolicy opponent: the whole step is one launch (with the agent's draw in it when it comes as logits)
+            tail = (mnk_hip.ptr(self.pending_resets), mnk_hip.ptr(self.agent_side), mnk_hip.ptr(forced), self.seed, step,
+                    mnk_hip.ptr(self.step_dev), self.env_id0, mnk_hip.ptr(rewards), mnk_hip.ptr(terminated),
+                    mnk_hip.ptr(obs), mnk_hip.obs_code(obs), mnk_hip.ptr(mask), mnk_hip.ptr(packed), mnk_hip.ptr(env._err),
+                    mnk_hip.ptr(self._ep_return), mnk_hip.ptr(self._ep_length), mnk_hip.ptr(self._ep_stats), env._flags(),
+                    env._stream())
+            if agent_draw is None:
+                mnk_hip.call("mnk_selfplay_step_random", *geo, mnk_hip.ptr(actions), *tail)
+            else:
+                mnk_hip.call("mnk_selfplay_step_random_logits", *geo, *agent_draw, *tail)
         else:
             if opp is None:
                 raise RuntimeError("TorchSelfPlayWrapper: set_opponent(policy) before reset()/step()")
             opp_obs = torch.empty((n, 2, env.m, env.n), dtype=env.obs_dtype, device=dev)
             opp_mask = torch.empty((n, env.max_moves), dtype=torch.bool, device=dev)
-            mnk_hip.call("mnk_selfplay_pre", mnk_hip.ptr(env._planes), mnk_hip.ptr(env._meta), n, env.m, env.n,
-                         env.k, mnk_hip.ptr(actions), mnk_hip.ptr(self.pending_resets), mnk_hip.ptr(self.agent_side),
-                         mnk_hip.ptr(forced), self.seed, step, mnk_hip.ptr(self.step_dev), self.env_id0,
-                         mnk_hip.ptr(rewards),
-                         mnk_hip.ptr(terminated), mnk_hip.ptr(self._flags), mnk_hip.ptr(opp_obs),
-                         mnk_hip.obs_code(opp_obs), mnk_hip.ptr(opp_mask), mnk_hip.ptr(env._err), env._flags(),
-                         env._stream())
-            with torch.no_grad():  # wrapper:91-94: one positional argument, no `deterministic`
-                opp_actions = opp.act({"observation": opp_obs, "action_mask": opp_mask})
-            opp_actions = torch.as_tensor(opp_actions, device=dev).to(torch.long).reshape(-1).contiguous()
-            if opp_actions.numel() != n:
-                raise IndexError(f"opponent policy returned {opp_actions.numel()} actions for {n} rows")
-            mnk_hip.call("mnk_selfplay_post", mnk_hip.ptr(env._planes), mnk_hip.ptr(env._meta), n, env.m, env.n,
-                         env.k, mnk_hip.ptr(opp_actions), mnk_hip.ptr(self._flags), mnk_hip.ptr(self.agent_side),
-                         mnk_hip.ptr(rewards), mnk_hip.ptr(terminated), mnk_hip.ptr(self.pending_resets),
-                         mnk_hip.ptr(obs), mnk_hip.obs_code(obs), mnk_hip.ptr(mask), mnk_hip.ptr(packed),
-                         mnk_hip.ptr(env._err), mnk_hip.ptr(self._ep_return),
-                         mnk_hip.ptr(self._ep_length), mnk_hip.ptr(self._ep_stats), env._flags(), env._stream())
+            tail = (mnk_hip.ptr(self.pending_resets), mnk_hip.ptr(self.agent_side), mnk_hip.ptr(forced), self.seed, step,
+                    mnk_hip.ptr(self.step_dev), self.env_id0, mnk_hip.ptr(rewards), mnk_hip.ptr(terminated),
+                    mnk_hip.ptr(self._flags), mnk_hip.ptr(opp_obs), mnk_hip.obs_code(opp_obs), mnk_hip.ptr(opp_mask),
+                    mnk_hip.ptr(env._err), env._flags(), env._stream())
+            if agent_draw is None:
+                mnk_hip.call("mnk_selfplay_pre", *geo, mnk_hip.ptr(actions), *tail)
+            else:
+                mnk_hip.call("mnk_selfplay_pre_logits", *geo, *agent_draw, *tail)
+            tail = (mnk_hip.ptr(self._flags), mnk_hip.ptr(self.agent_side), mnk_hip.ptr(rewards), mnk_hip.ptr(terminated),
+                    mnk_hip.ptr(self.pending_resets), mnk_hip.ptr(obs), mnk_hip.obs_code(obs), mnk_hip.ptr(mask),
+                    mnk_hip.ptr(packed), mnk_hip.ptr(env._err), mnk_hip.ptr(self._ep_return), mnk_hip.ptr(self._ep_length),
+                    mnk_hip.ptr(self._ep_stats), env._flags(), env._stream())
+            opp_view = {"observation": opp_obs, "action_mask": opp_mask}
+            if getattr(opp, "fused_logits", False) and self.fuse_opponent_draw:
+                # FusedNNPolicy opponent: only its forward is the caller's; mask + softmax + draw happen inside the post
+                # kernel (wrapper:91-96 + policy.py:46-52 + cnn.py:69-79), on the opponent's own sampler stream
+                from selfplay.policy import HipSampler
+
+                opp_logits, dtype, _ = HipSampler.prepare(opp.logits(opp_view), opp_mask)
+                if opp_logits is not None and opp_logits.shape != (n, env.max_moves):  # (None: a uniformly random head)
+                    raise IndexError(f"opponent policy returned logits {tuple(opp_logits.shape)} for {n} rows")
+                opp_actions = torch.empty(n, dtype=torch.long, device=dev)
+                sampler = opp._sampler
+                mnk_hip.call("mnk_selfplay_post_logits", *geo, mnk_hip.ptr(opp_logits), dtype, mnk_hip.ptr(opp_mask),
+                             *sampler.block(False), mnk_hip.ptr(opp_actions), None, *tail)
+                sampler.advance()
+            else:
+                with torch.no_grad():  # wrapper:91-94: one positional argument, no `deterministic`
+                    opp_actions = opp.act(opp_view)
+                opp_actions = torch.as_tensor(opp_actions, device=dev).to(torch.long).reshape(-1).contiguous()
+                if opp_actions.numel() != n:
+                    raise IndexError(f"opponent policy returned {opp_actions.numel()} actions for {n} rows")
+                mnk_hip.call("mnk_selfplay_post", *geo, mnk_hip.ptr(opp_actions), *tail)
+            self.last_opponent_actions = opp_actions  # (debugging / tests: rows without MNK_SP_NEED_OPP were not played)
         if env.strict:
             env.check_errors()
         # truncated (wrapper:66) is all-False by construction: one persistent tensor instead of a memset per step

@@ -36,7 +36,8 @@ def test_header_declares_the_path():
     for name in ("mnk_step", "mnk_observe", "mnk_reset_all", "mnk_reset_idx", "mnk_sample_legal",
                  "mnk_rollout_random", "mnk_replay_actions", "mnk_selfplay_pre", "mnk_selfplay_post", "mnk_sample_logits",
                  "mnk_pack_boards", "mnk_unpack_boards", "mnk_unpack_records", "mnk_gather_obs", "mnk_gae",
-                 "mnk_step_random", "mnk_selfplay_step_random"):
+                 "mnk_step_random", "mnk_selfplay_step_random", "mnk_selfplay_pre_logits", "mnk_selfplay_post_logits",
+                 "mnk_selfplay_step_random_logits"):
         assert name in decl
 
 
@@ -96,7 +97,7 @@ def test_header_is_plain_c(tmp_path):
     import subprocess
 
     src = tmp_path / "hdr.c"
-    src.write_text('#include "mnk_hip.h"\nint main(void) { return MNK_ABI_VERSION == 4 ? 0 : 1; }\n')
+    src.write_text('#include "mnk_hip.h"\nint main(void) { return MNK_ABI_VERSION == 5 ? 0 : 1; }\n')
     inc = os.path.join(ROOT, "include")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)], check=True)
     subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)], check=True)
@@ -115,5 +116,5 @@ def test_a_plain_c_host_links_against_the_library():
     res = subprocess.run([exe, "--abi"], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr
     got = dict(kv.split("=") for kv in res.stdout.split())
-    assert got == {"abi": "4", "header_abi": "4", "words_9x9": "2", "record_words_9x9": "3", "words_19x19": "6",
+    assert got == {"abi": "5", "header_abi": "5", "words_9x9": "2", "record_words_9x9": "3", "words_19x19": "6",
                    "supported_9x9x5": "1", "supported_2x2x3": "0"}

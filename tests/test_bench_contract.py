@@ -105,3 +105,32 @@ def test_rehearsed_exchange_lines_time_both_forms():
         assert x["alone"]["ncclAllGather_ms"] > 0 and x["alone"]["direct_sendrecv_ms"] > 0
     assert sorted(d["gather"] for d in lines) == ["actions", "actions", "actions", "records"]
     assert {round(d["exchange"]["bytes_per_env_step"], 3) for d in lines} == {0.893, 1.016, 28.0}
+
+
+def test_round4_line_uses_one_clock_and_stays_under_the_peak():
+    """Round 4: the roofline fraction is given on BOTH clocks of the line, named -- `frac` =
+    frac_kernel_events (HIP events on the kernel's stream, the contract's definition), frac_wall from `ms_per_step`, the
+    interval `value` is computed from -- the wall-clock one cannot exceed the kernel's, and neither exceeds the peak."""
+    d = _line("r04_bench_line.json")
+    r = d["roofline"]
+    assert r["frac"] == r["frac_kernel_events"] == pytest.approx(r["achieved"] / r["peak"])
+    wall = r["alg_bytes_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e9
+    assert wall <= r["peak"] and r["achieved_wall"] == pytest.approx(wall, rel=1e-9)
+    assert r["frac_wall"] == pytest.approx(wall / r["peak"]) and r["frac_wall"] <= r["frac_kernel_events"]
+    assert d["value"] == pytest.approx(d["config"]["envs_per_gpu"] * d["config"]["chunk"] / (d["ms_per_step"] * 1e-3), rel=1e-6)
+    sp = d["selfplay"]
+    assert sp["launches_per_agent_step"] == 1
+    tc = sp["train_cadence_384_envs"]
+    assert tc["one_graph_inplace_opponent_swap_us"] < tc["eager_reference_loop_us"] < tc["recapture_per_rollout_us"] * 1.5
+    assert tc["speedup_swap_vs_eager"] > 1.5 and tc["env_side_launches_per_agent_step"] == 2
+
+
+def test_round4_profile_summary_splits_the_phases():
+    """the tracked summary's timed-region dispatch time is at most the same run's ms_per_step"""
+    import re
+
+    text = open(os.path.join(ROOT, "profiles", "r04_rollout_9x9x5.md")).read()
+    m = re.search(r"\| TIMED REGION \| (\d+) \| ([\d.]+) \|", text)
+    assert m and int(m.group(1)) == 64
+    line = json.loads(re.search(r"```json\n(.*?)\n```", text, flags=re.S).group(1))
+    assert float(m.group(2)) <= line["ms_per_step"] * 1e3

@@ -430,3 +430,97 @@ def test_graphed_rollout_fills_the_buffer_like_the_eager_loop(hip, agent, oppone
             assert torch.equal(buf.observations, buf2.observations) and torch.equal(buf.action_masks, buf2.action_masks), where
         nxt_graph = roll.next_obs()
         assert torch.equal(nxt_graph["observation"], obs["observation"]) and torch.equal(nxt_graph["action_mask"], obs["action_mask"]), where
+
+
+# ----------------------------------------------------------------------------- round 4: sink hardening
+def _copying_loop(hip, wrap, buf, agent, obs, rollouts, fields):
+    """the reference-shaped loop (alg/ppo.py:93-108, :148): act, step, add, ... then buffer.reset()"""
+    zeros = torch.zeros(wrap.num_envs, device=DEV)
+    snaps = []
+    for _ in range(rollouts):
+        for _ in range(buf.n_steps):
+            actions = agent.act(obs)
+            nxt, rew, term, trunc, _ = wrap.step(actions)
+            buf.add(obs["observation"], actions, rew, zeros, zeros, term | trunc, obs["action_mask"])
+            obs = nxt
+        snaps.append({f: getattr(buf, f)[:buf.n_steps].clone() for f in fields})
+        buf.reset()
+    return snaps, obs
+
+
+@pytest.mark.parametrize("n_steps", [1, 2, 3])
+@pytest.mark.parametrize("opponent", ["random", "scripted"])
+def test_consecutive_short_rollouts_through_the_sink_equal_the_copying_loop(hip, n_steps, opponent):
+    """with ``n_steps == 1`` the observation acted on at t = 0 of every rollout after the first IS the
+    spill row, which the same step would overwrite before ``add`` reads it.  A one-step buffer therefore keeps two spill
+    rows and uses them in turn: rollouts of 1, 2 and 3 steps through the sink equal the reference-shaped copying loop
+    (no sink: fresh tensors per step, ``add`` copies everything), every field, every rollout."""
+    m, n, k, nenv, rollouts = 9, 9, 5, 300, 5
+    c = m * n
+    fields = ("observations", "action_masks", "actions", "rewards", "dones")
+    got = {}
+    for sink in (True, False):
+        wrap = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV), seed=11)
+        wrap.set_opponent(hip.policy.RandomPolicy(c, seed=12) if opponent == "random" else MaskHashPolicy())
+        buf = hip.Buffer(n_steps, nenv, (2, m, n), c, device=DEV)
+        if sink:
+            wrap.attach_sink(buf)
+        obs, _ = wrap.reset()
+        got[sink], last = _copying_loop(hip, wrap, buf, hip.policy.RandomPolicy(c, seed=13), obs, rollouts, fields)
+        got[sink].append({"observations": last["observation"].clone(), "action_masks": last["action_mask"].clone()})
+        if sink:
+            assert buf.copied_bytes < rollouts * n_steps * nenv * 17 + rollouts * nenv * 729 + 1  # per rollout at most one observation copy
+    for j, (a, b) in enumerate(zip(got[True], got[False])):
+        for f in a:
+            assert torch.equal(a[f], b[f]), (j, f)
+
+
+@pytest.mark.parametrize("obs_dtype", [torch.float32] + NARROW)
+@pytest.mark.parametrize("packed", [False, True])
+def test_buffer_reset_keeps_the_observation_the_caller_acts_on(hip, obs_dtype, packed):
+    """``buffer.reset()`` between ``learn`` calls (ppo.py:148) zeroes the storage in place while a sink is attached -- but
+    never the row that holds the observation handed out last: the spill row after a full rollout, row 0 right after
+    ``wrapper.reset()`` (a caller that resets the buffer at the START of its rollout), any row in between.  f32, bf16 and
+    u8 observations; dense and packed buffers."""
+    m, n, k, nenv, steps = 9, 9, 5, 200, 4
+    c = m * n
+    if packed and obs_dtype != torch.float32:
+        pytest.skip("the packed buffer stores planes, not observations")
+    wrap = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV, obs_dtype=obs_dtype), seed=5)
+    wrap.set_opponent(hip.policy.RandomPolicy(c, seed=6))
+    buf = hip.PackedBuffer(steps, nenv, m, n, device=DEV) if packed else hip.Buffer(steps, nenv, (2, m, n), c, device=DEV, obs_dtype=obs_dtype)
+    store = buf._plane_store if packed else buf._obs_store
+    wrap.attach_sink(buf)
+    assert buf.keep_storage
+    agent = hip.policy.RandomPolicy(c, seed=7)
+    zeros = torch.zeros(nenv, device=DEV)
+
+    def current():
+        return wrap.packed_obs() if packed else wrap.get_agent_obs()["observation"]
+
+    obs, _ = wrap.reset()
+    base = store.data_ptr()
+    for stop in (0, 2, steps):          # reset right after wrapper.reset(), mid-rollout, after a full rollout
+        for _ in range(stop):
+            actions = agent.act(obs)
+            key = store[buf._live].clone()
+            nxt, rew, term, trunc, _ = wrap.step(actions)
+            if packed:
+                buf.add(key, actions, rew, zeros, zeros, term | trunc)
+            else:
+                buf.add(obs["observation"], actions, rew, zeros, zeros, term | trunc, obs["action_mask"])
+            obs = nxt
+        live = buf._live
+        buf.reset()
+        assert store.data_ptr() == base and buf.ptr == 0            # same storage
+        assert torch.equal(store[live], current())                 # the observation to act on is still there
+        others = [r for r in range(steps) if r != live]
+        assert not bool(store[others].any())                       # everything else was zeroed
+        if not packed:
+            assert torch.equal(obs["observation"], current()) and bool(obs["action_mask"].any(dim=1).all())
+    # without a sink the buffer allocates fresh tensors like the reference: views kept by the caller keep their data
+    plain = hip.Buffer(steps, nenv, (2, m, n), c, device=DEV)
+    plain.add(torch.ones(nenv, 2, m, n, device=DEV), zeros.long(), zeros, zeros, zeros, zeros.bool(), torch.ones(nenv, c, dtype=torch.bool, device=DEV))
+    kept = plain.observations
+    plain.reset()
+    assert bool((kept[0] == 1).all()) and not bool(plain.observations.any()) and plain.observations.data_ptr() != kept.data_ptr()

@@ -16,6 +16,42 @@ def counters(d, kernel_substr):
     return {k: (sum(v) / len(v), len(v)) for k, v in out.items()}
 
 
+def phases(root, kern, bench):
+    """The dominant kernel's dispatches of the kernel-trace pass, split by the phase of bench.py they belong to (in
+    dispatch order: --settle set-up launches at ramping clocks, --warmup launches, the --steps launches of the timed
+    region, then the four repetitions): one average over all of them mixes the cold launches with the timed ones and
+    reads higher than the run's own ms_per_step."""
+    files = sorted(glob.glob(os.path.join(root, "trace", "**", "*_kernel_trace.csv"), recursive=True), key=os.path.getmtime)
+    if not files or not bench:
+        return
+    rows = [r for r in csv.DictReader(open(files[-1])) if kern in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    us = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+    settle, warm, steps = bench.get("setup_launches", 0), bench["warmup"], bench["steps"]
+    cuts = [("set-up (--settle: clocks ramping)", settle), ("warm-up", warm), ("TIMED REGION", steps), ("repetitions + extras", len(us))]
+    print(f"## `{kern}` dispatches by bench phase (kernel-trace pass, in dispatch order)\n")
+    print("| phase | dispatches | mean us | median us | min us | max us |\n|---|---|---|---|---|---|")
+    lo = 0
+    timed_mean = None
+    for name, count in cuts:
+        part = us[lo:lo + count]
+        lo += count
+        if not part:
+            continue
+        srt = sorted(part)
+        mean = sum(part) / len(part)
+        if name == "TIMED REGION":
+            timed_mean = mean
+        print(f"| {name} | {len(part)} | {mean:.2f} | {srt[len(srt) // 2]:.2f} | {srt[0]:.2f} | {srt[-1]:.2f} |")
+    if timed_mean is not None:
+        step_us = bench["ms_per_step"] * 1e3
+        alg = bench["roofline"]["alg_bytes_per_launch"]
+        print(f"\ntimed region under the profiler: {timed_mean:.2f} us per dispatch = {alg / timed_mean / 1e3:.0f} GB/s = "
+              f"{alg / timed_mean / 1e3 / 8000:.3f} of 8 TB/s; the same run's ms_per_step (wall clock, barrier to barrier): "
+              f"{step_us:.2f} us ({'>=' if step_us >= timed_mean else '<'} the kernel's own time); in-bench HIP events: "
+              f"{bench['roofline']['avg_launch_us']:.2f} us\n")
+
+
 def main():
     root, tag = sys.argv[1], sys.argv[2]
     kern = sys.argv[3] if len(sys.argv) > 3 else "k_rollout_random"
@@ -35,6 +71,7 @@ def main():
             print(f"| `{name}` | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | "
                   f"{float(r['Percentage']):.2f} | {r['MinNs']} | {r['MaxNs']} |")
         print()
+    phases(root, kern, bench)
     print(f"## counters of `{kern}` (mean per dispatch; separate `--pmc` passes, 4 timed launches each)\n")
     print("| counter | mean | dispatches |\n|---|---|---|")
     allc = {}
