@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 # (FETCH_SIZE x 1024 x 2 [gfx950 correction] + WRITE_SIZE x 1024), keyed by (board, envs/GPU, chunk).
 # bench.py cannot run rocprofv3 on itself; configurations without a committed profile report null.
 PMC_TRAFFIC = {
-    ("9x9x5", 65536, 256): (474.71e6, "profiles/r03_rollout_9x9x5.md"),
+    ("9x9x5", 65536, 256): (474.71e6, "profiles/r04_rollout_9x9x5.md"),
     ("19x19x5", 32768, 256): (845.87e6, "profiles/r03_rollout_19x19x5_32768.md"),   # two lanes per env, words split
     ("12x12x5", 65536, 256): (745.25e6, "profiles/r02_rollout_12x12x5_jit.md"),     # run-time specialised kernel
 }

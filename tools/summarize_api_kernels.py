@@ -50,7 +50,7 @@ BYTES = {
 
 
 def short(name):
-    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "").replace(", NoDraw>", ">")
     return re.sub(r"\(.*$", "", name)
 
 
