@@ -729,9 +729,10 @@ def selfplay_config3(args, steps, warm):
             buf.ptr = 0  # the next rollout overwrites the rows (values / advantages are not part of this measurement)
         before = env._meta >> 1
         prev = state["obs"]
-        actions = agent.act(prev)
-        state["obs"], rew, term, trunc, _ = wrap.step(actions)
-        buf.add(prev["observation"], actions, rew, zeros, zeros, term | trunc, prev["action_mask"])
+        # the agent's forward is the caller's; its mask + softmax + draw happen inside the step kernel, and so do the
+        # opponent's (FusedNNPolicy): two env-side launches per agent-step
+        state["obs"], rew, term, trunc, info = wrap.step_logits(agent.logits(prev), prev["action_mask"], agent._sampler)
+        buf.add(prev["observation"], info["actions"], rew, zeros, info["log_probs"], term | trunc, prev["action_mask"])
         # plies played this step = growth of the move counters (resets restart them at 0 or 1)
         state["plies"] += torch.clamp((env._meta >> 1) - before, min=0).sum()
 

@@ -424,3 +424,40 @@ def test_graphed_rollout_checkpoint_continues_its_streams(hip, tmp_path):
     obs = _eager_rollout(hip, w3, b3, net, agent, obs)
     for f in FIELDS:
         assert torch.equal(getattr(b3, f)[:steps], want[0][f]), f
+
+
+def test_graphed_agent_step_swaps_its_opponent_in_place(hip):
+    """``GraphedAgentStep.set_opponent_weights``: the one-step-per-graph collector after an in-place opponent swap equals
+    the eager loop after ``set_opponent(FusedNNPolicy(deepcopy(source), seed=s))`` -- no new capture."""
+    m, n, k, nenv = 9, 9, 5, 130
+    net = TinyNet(m, n, 10).to(DEV).eval()
+    first, second = TinyNet(m, n, 20).to(DEV).eval(), TinyNet(m, n, 21).to(DEV).eval()
+    wg = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV), seed=17)
+    wg.set_opponent(hip.policy.FusedNNPolicy(copy.deepcopy(first), seed=50))
+    col = hip.graphed.GraphedAgentStep(wg, net, seed=60)       # (its warm-up plays 4 steps)
+    graphs = list(col.graphs)
+    outs = []
+    for t in range(12):
+        if t == 5:
+            col.set_opponent_weights(second, seed=51)
+        o = col.step()
+        outs.append({key: o[key].clone() for key in ("obs", "mask", "actions", "log_probs", "rewards", "terminated")})
+    assert col.graphs == graphs
+
+    we = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV), seed=17)
+    we.set_opponent(hip.policy.FusedNNPolicy(copy.deepcopy(first), seed=50))
+    agent = hip.policy.HipSampler(seed=60)
+    obs, _ = we.reset()
+    for t in range(4 + 12):
+        if t == 4 + 5:
+            we.set_opponent(hip.policy.FusedNNPolicy(copy.deepcopy(second), seed=51))
+        with torch.no_grad():
+            dist, _ = net(obs["observation"], None)
+        actions, logp = agent.draw(dist.logits, obs["action_mask"], False, want_logp=True)
+        prev = obs
+        obs, rew, term, _, _ = we.step(actions)
+        if t >= 4:
+            o = outs[t - 4]
+            assert torch.equal(o["obs"], prev["observation"]) and torch.equal(o["mask"], prev["action_mask"]), t
+            assert torch.equal(o["actions"], actions) and torch.equal(o["log_probs"], logp), t
+            assert torch.equal(o["rewards"], rew) and torch.equal(o["terminated"], term), t

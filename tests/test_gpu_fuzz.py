@@ -172,6 +172,9 @@ def test_wrapper_fuzz(hip, seed):
     ora = _ForcedSides(OracleVectorEnv(m, n, k, nenv))
     wrap.set_opponent(opp())
     ora.set_opponent(opp())
+    from selfplay.policy import HipSampler
+
+    sampler = HipSampler(seed=seed)
     sides = torch.from_numpy(rng.integers(0, 2, nenv))
     wrap.force_sides(sides)
     ora.sides = sides
@@ -188,7 +191,17 @@ def test_wrapper_fuzz(hip, seed):
         out = None
         if rng.random() < 0.4:  # a random subset of the outputs goes to caller-owned tensors
             out = {key: t_ for key, t_ in mine.items() if rng.random() < 0.6}
-        o1, r1, t1, tr1, _ = wrap.step(torch.from_numpy(acts).to(DEV), out=out)
+        if rng.random() < 0.35:
+            # round 4: the same moves through the step kernels with the draw folded in (mnk_selfplay_pre_logits; two
+            # launches inside the call on boards without a compile-time draw shape): logits whose argmax is the move,
+            # an all-True mask (the mask is an input of the draw: occupied cells stay playable as in wrapper.step)
+            logits = torch.zeros((nenv, c), dtype=torch.bfloat16 if rng.random() < 0.5 else torch.float32, device=DEV)
+            logits[torch.arange(nenv, device=DEV), torch.from_numpy(acts).to(DEV)] = 10.0
+            o1, r1, t1, tr1, info = wrap.step_logits(logits, torch.ones((nenv, c), dtype=torch.bool, device=DEV), sampler,
+                                                     deterministic=True, out=out)
+            assert np.array_equal(info["actions"].cpu().numpy(), acts), where
+        else:
+            o1, r1, t1, tr1, _ = wrap.step(torch.from_numpy(acts).to(DEV), out=out)
         o2, r2, t2, tr2, _ = ora.step(torch.from_numpy(acts))
         want_dtype = out["observation"].dtype if out and "observation" in out else obs_dtype
         assert o1["observation"].dtype == want_dtype, where
