@@ -214,18 +214,25 @@ __device__ __forceinline__ Drawn draw_row(const float* lrow, int C, float u, int
   } else {
     const float incl = group_scan<LPR>(mine, sub);
     const float target = u * total_w;
-    // first lane whose inclusive sum passes the target
-    const unsigned long long pass = __ballot(incl > target && mine > 0.0f);
-    const uint32_t pass_g = (uint32_t)((pass >> gbase) & gmask);
-    int owner = __ffs(pass_g) - 1;
     // cells of this lane whose running sum stays at or below the target = index of the first one above it
-    float run = incl - mine;
+    const float base = incl - mine;  // the lanes before this one
+    float run = base;
     int cnt = 0;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       run += w[j];
       cnt += (run <= target) ? 1 : 0;
     }
+    // The lane that holds the target: the lanes before it end at or below it and ITS OWN running sum -- the very values
+    // the count above compared, not the scan's `incl`, which is the same sum in another association -- ends above it.
+    // Then the count stops at a cell that moved the sum, i.e. a cell with weight: never a masked cell, never one of the
+    // cells past the end of the row that the lane's last slot stands for.  (Round 3 tested `incl > target`: when the two
+    // associations differed in the last bit and the target fell between them, the count ran through and the pick was
+    // the lane's last slot -- cell C..C+LPR-2, an out-of-range action, about once in 10^7 draws on 3x3.)  If rounding
+    // leaves no lane with both properties, the fallback below takes the last cell with weight.
+    const unsigned long long pass = __ballot(run > target && base <= target && mine > 0.0f);
+    const uint32_t pass_g = (uint32_t)((pass >> gbase) & gmask);
+    int owner = __ffs(pass_g) - 1;
     if (__ballot(pass_g == 0u) != 0ull) {
       // rounding left the target at or beyond the total: the last cell with weight of the last lane with weight
       const unsigned long long heavy = __ballot(mine > 0.0f);

@@ -72,6 +72,7 @@ struct MnkConfig {
   bool saddr_off = false;  // MNK_ROLLOUT_SADDR=0: no 32-bit-offset record stores
   int emit_envs = 0;       // MNK_EMIT_ENVS=16|32|64|128: envs per workgroup of the write-out kernels (0: by batch size)
   int emit_threads = 0;    // MNK_EMIT_THREADS=64|128|256 (the kernels are __launch_bounds__(256); 0: by output set)
+  int gae_depth = 0;       // MNK_GAE_DEPTH=8|16|32: steps of loads mnk_gae keeps in flight per batch (0: the default)
 };
 enum { MNK_FORM_NONE = 0, MNK_FORM_LANE, MNK_FORM_PAIR, MNK_FORM_PAIRW, MNK_FORM_WS2, MNK_FORM_WS4 };
 
@@ -88,6 +89,10 @@ inline MnkConfig mnk_read_config() {
   if (const char* v = getenv("MNK_EMIT_ENVS")) {
     const int t = atoi(v);
     c.emit_envs = (t == 16 || t == 32 || t == 64 || t == 128) ? t : 0;
+  }
+  if (const char* v = getenv("MNK_GAE_DEPTH")) {
+    const int t = atoi(v);
+    c.gae_depth = (t == 8 || t == 16 || t == 32) ? t : 0;
   }
   if (const char* v = getenv("MNK_EMIT_THREADS")) {
     const int t = atoi(v);

@@ -243,17 +243,18 @@ k_gather_obs(MnkGeom g, const uint64_t* planes, int64_t T, int64_t N, const int6
 // The recurrence is a chain of two dependent f32 ops per step, but the loads do not depend on it: they are
 // issued GAE_DEPTH steps ahead (24 loads in flight per lane) -- with one step's loads in flight at a time
 // the loop ran at one HBM round trip per step (104 us for 256 x 65 536 instead of ~60 us of traffic).
-#define GAE_DEPTH 8
+template <int DEPTH>
 struct GaeBatch {
-  float r[GAE_DEPTH], v[GAE_DEPTH];
-  uint8_t d[GAE_DEPTH];
+  float r[DEPTH], v[DEPTH];
+  uint8_t d[DEPTH];
 };
 
-// the GAE_DEPTH steps t, t-1, ..., t-GAE_DEPTH+1 of env i (all loads independent of the recurrence)
-__device__ __forceinline__ void gae_load(GaeBatch& b, const float* rewards, const float* values, const uint8_t* dones,
+// the DEPTH steps t, t-1, ..., t-DEPTH+1 of env i (all loads independent of the recurrence)
+template <int DEPTH>
+__device__ __forceinline__ void gae_load(GaeBatch<DEPTH>& b, const float* rewards, const float* values, const uint8_t* dones,
                                          int64_t N, int64_t i, int t) {
 #pragma unroll
-  for (int j = 0; j < GAE_DEPTH; ++j) {
+  for (int j = 0; j < DEPTH; ++j) {
     const int64_t o = (int64_t)(t - j) * N + i;
     b.r[j] = rewards[o];
     b.v[j] = values[o];
@@ -262,9 +263,12 @@ __device__ __forceinline__ void gae_load(GaeBatch& b, const float* rewards, cons
 }
 
 // The recurrence is a chain of two dependent f32 ops per step, but the loads do not depend on it.  Round 1 issued one
-// batch of GAE_DEPTH steps' loads, waited for it, computed, stored: one HBM round trip per batch (57-80 us for
-// 256 x 65 536 against ~45 us of traffic).  Now the next batch's loads are in flight while the current batch is
-// computed and stored (two register sets): the round trip hides behind the arithmetic and the stores.
+// batch of 8 steps' loads, waited for it, computed, stored: one HBM round trip per batch (57-80 us for
+// 256 x 65 536 against ~45 us of traffic).  Round 2: the next batch's loads are in flight while the current batch is
+// computed and stored (two register sets): the round trip hides behind the arithmetic and the stores.  Round 4: DEPTH is
+// a template parameter (MNK_GAE_DEPTH=8|16|32 for A/B): one lane per env gives 1 024 waves at 65 536 envs, and what
+// bounds the kernel is the bytes those waves keep in flight (9 B per step and lane).
+template <int DEPTH>
 __global__ void __launch_bounds__(64)
 k_gae(const float* rewards, const float* values, const uint8_t* dones, const float* last_values, int64_t N, int T,
       float gamma, float gamma_lambda, float* advantages, float* returns) {
@@ -273,13 +277,13 @@ k_gae(const float* rewards, const float* values, const uint8_t* dones, const flo
   float run = 0.0f;
   float next_v = last_values[i];
   int t = T - 1;
-  GaeBatch cur, nxt;
-  if (t >= GAE_DEPTH - 1) gae_load(cur, rewards, values, dones, N, i, t);
-  for (; t >= GAE_DEPTH - 1; t -= GAE_DEPTH) {
-    const bool more = t - GAE_DEPTH >= GAE_DEPTH - 1;
-    if (more) gae_load(nxt, rewards, values, dones, N, i, t - GAE_DEPTH);
+  GaeBatch<DEPTH> cur, nxt;
+  if (t >= DEPTH - 1) gae_load<DEPTH>(cur, rewards, values, dones, N, i, t);
+  for (; t >= DEPTH - 1; t -= DEPTH) {
+    const bool more = t - DEPTH >= DEPTH - 1;
+    if (more) gae_load<DEPTH>(nxt, rewards, values, dones, N, i, t - DEPTH);
 #pragma unroll
-    for (int j = 0; j < GAE_DEPTH; ++j) {
+    for (int j = 0; j < DEPTH; ++j) {
       const int64_t o = (int64_t)(t - j) * N + i;
       const float nonterm = 1.0f - (cur.d[j] ? 1.0f : 0.0f);            // :72
       const float delta = cur.r[j] + gamma * next_v * nonterm - cur.v[j];  // :74
@@ -586,8 +590,16 @@ int mnk_gae(const float* rewards, const float* values, const uint8_t* dones, con
   if (!rewards || !values || !dones || !last_values || !advantages || !returns || N < 0 || T < 0) return MNK_EINVAL;
   if (N == 0 || T == 0) return MNK_OK;
   const int B = 64;
-  hipLaunchKernelGGL(k_gae, dim3((unsigned)((N + B - 1) / B)), dim3(B), 0, (hipStream_t)stream, rewards, values, dones,
-                     last_values, N, T, gamma, gamma_lambda, advantages, returns);
+  const dim3 grid((unsigned)((N + B - 1) / B));
+  const int depth = mnk_config().gae_depth;
+#define MNK_GAE(D) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gae<D>), grid, dim3(B), 0, (hipStream_t)stream, rewards, values, dones, \
+                                      last_values, N, T, gamma, gamma_lambda, advantages, returns)
+  // (A/B at 256 x 65 536, profiles/r04_exp_gae.log: depth 8 49.9 us, 16 59.4, 32 52.7 -- more loads in flight per wave do
+  // not help: 8 stays)
+  if (depth == 16) MNK_GAE(16);
+  else if (depth == 32) MNK_GAE(32);
+  else MNK_GAE(8);
+#undef MNK_GAE
   return mnk_launch_status("gae");
 }
 

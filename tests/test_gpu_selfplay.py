@@ -1026,6 +1026,30 @@ def test_sampler_all_row_widths(hip, m, n):
     assert torch.equal(first, want)
 
 
+@pytest.mark.parametrize("c", [9, 81, 169])
+def test_drawn_cells_always_carry_weight(hip, c):
+    """Round 4 regression: the lane that holds the target was found with the scan's inclusive sum while the cell inside it
+    was found with a sequentially accumulated one -- the same number in two associations.  When they differed in the last
+    bit and the target fell between them the pick ran through to the lane's last slot, which stands for a cell PAST the
+    end of the row (action C .. C+LPR-2: out of range) -- about once in 10^7 draws on 3x3, found by
+    examples/selfplay_ppo_graphed.py.  Tens of millions of draws from peaked, half-masked rows: every action is a legal
+    cell of its row, f32 and bf16 logits."""
+    rows = 1 << 21 if c <= 81 else 1 << 20
+    g = torch.Generator(device="cpu").manual_seed(c)
+    logits = (torch.randn(rows, c, generator=g) * 6).to(DEV)
+    mask = (torch.rand(rows, c, generator=g) > 0.5)
+    mask[torch.arange(rows), torch.randint(0, c, (rows,), generator=g)] = True
+    mask = mask.to(DEV)
+    sampler = hip.policy.HipSampler(seed=c)
+    for t in range(24):
+        lg = logits if t % 3 else logits.to(torch.bfloat16)
+        acts = sampler.draw(lg, mask, False)
+        assert int(acts.max()) < c and int(acts.min()) >= 0, t
+        assert bool(mask.gather(1, acts.unsqueeze(1)).all()), t
+    acts = sampler.draw(None, mask, False)  # the uniform form
+    assert bool(mask.gather(1, acts.unsqueeze(1)).all())
+
+
 def test_checkpoint_resume_is_bit_exact(hip, tmp_path):
     """state_dict / load_state_dict of the env, the wrapper (with episode accounting) and the rollout driver:
     a run restored from a checkpoint written to disk continues exactly like the run that wrote it."""

@@ -126,7 +126,39 @@ def cadence(*sizes):
               f"(x{t_eager / t_recap:.2f})", flush=True)
 
 
+def gae_depth(nenv=65536, T=256):
+    """mnk_gae by prefetch depth (MNK_GAE_DEPTH): 17 B per (t, env)"""
+    from selfplay.random_rollout import gae
+
+    g = torch.Generator().manual_seed(0)
+    r = torch.randn(T, nenv, generator=g).to(DEV)
+    v = torch.randn(T, nenv, generator=g).to(DEV)
+    d = (torch.rand(T, nenv, generator=g) < 0.02).to(DEV)
+    last = torch.randn(nenv, generator=g).to(DEV)
+    ref = None
+    for depth in ("8", "16", "32"):
+        os.environ["MNK_GAE_DEPTH"] = depth
+        mnk_hip.reload_config()
+        adv, ret = gae(r, v, d, last)
+        if ref is None:
+            ref = (adv.clone(), ret.clone())
+        assert torch.equal(adv, ref[0]) and torch.equal(ret, ref[1])
+        adv = torch.empty_like(r)
+        ret = torch.empty_like(r)
+
+        def launch():
+            mnk_hip.call("mnk_gae", mnk_hip.ptr(r), mnk_hip.ptr(v), mnk_hip.ptr(d), mnk_hip.ptr(last), nenv, T, 0.99, 0.99 * 0.95,
+                         mnk_hip.ptr(adv), mnk_hip.ptr(ret), mnk_hip.stream_ptr(torch.device(DEV)))
+
+        us = timeit(launch, reps=30, warm=5)
+        nbytes = 17 * T * nenv
+        print(f"mnk_gae {T} x {nenv} depth {depth:>2s}: {us:7.2f} us  {nbytes / us / 1e3:6.0f} GB/s  ({nbytes / us / 1e3 / 8000:.2f} of 8 TB/s)",
+              flush=True)
+    os.environ.pop("MNK_GAE_DEPTH", None)
+    mnk_hip.reload_config()
+
+
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "fused"
     args = [int(v) for v in sys.argv[2:]]
-    {"fused": fused, "cadence": cadence}[mode](*args)
+    {"fused": fused, "cadence": cadence, "gae": gae_depth}[mode](*args)
