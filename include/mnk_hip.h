@@ -89,7 +89,7 @@ extern "C" {
                          * [mnk_action_log_words(MNK_ACT_BITS7, T)][N] -- 0.875 B per env-step, what the ranks of
                          * BASELINE.json configs 2-4 (9x9: 81 cells) put on xGMI */
 
-#define MNK_ACT_U8P1 4  /* 9 bits per action, boards of more than 256 cells (19x19: 361): the low bytes as in MNK_ACT_U8,
+#define MNK_ACT_U8P1 4  /* 9 bits per action, boards of 257 to 512 cells (19x19: 361; larger boards take MNK_ACT_U16): the low bytes as in MNK_ACT_U8,
                          * u32[ceil(T/4)][N], followed by a bit plane of bit 8 of every action, ply p at bit p % 32 of
                          * word [ceil(T/4) + p / 32][i], u32[ceil(T/32)][N] -- 1.125 B per env-step where MNK_ACT_U16 takes 2
                          * (BASELINE.json config 5's exchange) */
@@ -129,7 +129,7 @@ int mnk_reload_config(void);
 int mnk_state_words(int m, int n);
 /* R = ceil(m*(n+1)/32), rows of one rollout record; 0 when the geometry is unsupported */
 int mnk_record_words(int m, int n);
-/* 1 when 1 <= k <= min(m,n), n <= 61 and W <= 8 (boards up to 22x22) */
+/* 1 when 1 <= k <= min(m,n), 2 <= n <= 61 and W <= 16 (planes of up to 1 024 bits m*(n+1): 22x22, 25x25, 31x31, 16x61) */
 int mnk_geometry_supported(int m, int n, int k);
 const char* mnk_last_launch_error(void);
 
@@ -193,7 +193,7 @@ int mnk_sample_legal(const uint64_t* planes, int64_t N, int m, int n, uint64_t s
 
 /* ---- alg/architectures/cnn.py:69-79 (= resnet.py:84-95, transformer.py:80-91) + policy.py:46-52 + ppo.py:96-97
  * Masked categorical head fused with the draw: logits [N][C] of type `logits_dtype` (MNK_LOGITS_F32: float,
- * MNK_LOGITS_BF16: bf16 bit patterns; any additive normalisation), mask u8[N][C], C <= 512.
+ * MNK_LOGITS_BF16: bf16 bit patterns; any additive normalisation), mask u8[N][C], C <= 1024.
  * logits == NULL: every logit is 0 -- a uniform draw over the legal cells (RandomPolicy, policy.py:13-29) that
  * reads only the mask.  deterministic != 0 -> argmax over legal cells (policy.py:48-49); else an inverse-CDF draw
  * from softmax(masked logits) with one Philox uniform per row (stream MNK_STREAM_SAMPLE).

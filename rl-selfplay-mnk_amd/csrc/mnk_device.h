@@ -32,8 +32,8 @@ typedef unsigned long long uintptr_t;
 #include "../../include/mnk_hip.h"
 #endif
 
-#define MNK_MAX_W 8     // u64 words per plane in memory
-#define MNK_MAX_NW 16   // u32 words per plane in registers
+#define MNK_MAX_W 16    // u64 words per plane in memory: boards of up to 1 024 bits m*(n+1) (25x25, 31x31)
+#define MNK_MAX_NW 32   // u32 words per plane in registers
 
 struct MnkGeom {
   int m, n, k;

@@ -148,14 +148,17 @@ inline int mnk_block_threads(bool writes_obs = true) {
     else if ((g).NW <= 2) MNK_CASE(2, 0, 0, __VA_ARGS__)                              \
     else if ((g).NW <= 4) MNK_CASE(4, 0, 0, __VA_ARGS__)                              \
     else if ((g).NW <= 8) MNK_CASE(8, 0, 0, __VA_ARGS__)                              \
-    else MNK_CASE(16, 0, 0, __VA_ARGS__)                                              \
+    else if ((g).NW <= 16) MNK_CASE(16, 0, 0, __VA_ARGS__)                            \
+    else MNK_CASE(32, 0, 0, __VA_ARGS__)                                              \
   } while (0)
 #define MNK_K(name) HIP_KERNEL_NAME(name<NW, CN, CK>)
-// the variants a board of more than 256 cells can have (MNK_ACT_U8P1): 19x19x5 and the generic 16-word form
+// the variants a board of more than 256 cells can have (MNK_ACT_U8P1, up to 512 cells): 19x19x5 and the generic 16- and
+// 32-word forms
 #define MNK_DISPATCH_LARGE(g, ...)                                                       \
   do {                                                                                   \
     if ((g).n == 19 && (g).k == 5 && (g).NW == 12) MNK_CASE(12, 19, 5, __VA_ARGS__)      \
-    else MNK_CASE(16, 0, 0, __VA_ARGS__)                                                 \
+    else if ((g).NW <= 16) MNK_CASE(16, 0, 0, __VA_ARGS__)                               \
+    else MNK_CASE(32, 0, 0, __VA_ARGS__)                                                 \
   } while (0)
 // the variants a board of at most 128 cells can have (the 7-bit action stream): 9x9x5, 3x3x3, generic up to 8 words
 #define MNK_DISPATCH_SMALL(g, ...)                                                    \
@@ -178,7 +181,7 @@ inline bool mnk_rollout_saddr_ok(const MnkGeom& g, int64_t N, int T) {
 // is `act` a log format this board can use?  (0 = no log)
 inline bool mnk_act_format_ok(int act, int C) {
   return act == 0 || act == MNK_ACT_U16 || (act == MNK_ACT_U8 && C <= 256) || (act == MNK_ACT_BITS7 && C <= 128) ||
-         (act == MNK_ACT_U8P1 && C > 256);  // (U8P1 would hold any board; only the boards that need it have kernel variants)
+         (act == MNK_ACT_U8P1 && C > 256 && C <= 512);  // (9 bits per action; only the boards that need it have kernel variants)
 }
 
 // A masked draw from a policy head's logits (mnk_sample_logits; the mnk_selfplay_*_logits entry points fold it into a
@@ -214,6 +217,30 @@ bool mnk_rollout_ws_supported(const MnkGeom& g, int act_bytes);
 void mnk_launch_rollout_ws(const MnkGeom& g, int ws, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed,
                            uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
                            void* act_log, int act_bytes, void* stream);
+
+// The rollout / replay kernels of boards with more than 16 register words per plane (planes of more than 512 bits) exist
+// as run-time specialisations only: their generic ahead-of-time forms took 20 minutes to compile for kernels nobody's
+// default board runs.  The API-level kernels keep a generic 32-word variant.
+#define MNK_DISPATCH16(g, ...)                                                        \
+  do {                                                                                \
+    if ((g).n == 9 && (g).k == 5 && (g).NW == 3) MNK_CASE(3, 9, 5, __VA_ARGS__)       \
+    else if ((g).n == 3 && (g).k == 3 && (g).NW == 1) MNK_CASE(1, 3, 3, __VA_ARGS__)  \
+    else if ((g).n == 13 && (g).k == 5 && (g).NW == 6) MNK_CASE(6, 13, 5, __VA_ARGS__) \
+    else if ((g).n == 15 && (g).k == 5 && (g).NW == 8) MNK_CASE(8, 15, 5, __VA_ARGS__) \
+    else if ((g).n == 19 && (g).k == 5 && (g).NW == 12) MNK_CASE(12, 19, 5, __VA_ARGS__) \
+    else if ((g).NW <= 2) MNK_CASE(2, 0, 0, __VA_ARGS__)                              \
+    else if ((g).NW <= 4) MNK_CASE(4, 0, 0, __VA_ARGS__)                              \
+    else if ((g).NW <= 8) MNK_CASE(8, 0, 0, __VA_ARGS__)                              \
+    else MNK_CASE(16, 0, 0, __VA_ARGS__)                                              \
+  } while (0)
+#define MNK_DISPATCH16_LARGE(g, ...)                                                     \
+  do {                                                                                   \
+    if ((g).n == 19 && (g).k == 5 && (g).NW == 12) MNK_CASE(12, 19, 5, __VA_ARGS__)      \
+    else MNK_CASE(16, 0, 0, __VA_ARGS__)                                                 \
+  } while (0)
+hipFunction_t mnk_jit_replay_function(const MnkGeom& g, bool rec, int act);
+int mnk_jit_launch_replay(hipFunction_t fn, MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, const void* act_log,
+                          uint64_t* rec_planes, uint32_t* rec_meta, int32_t* err, void* stream);
 
 // run-time specialised rollout kernels (mnk_jit.hip, hiprtc): nullptr when the compile failed
 hipFunction_t mnk_jit_rollout_function(const MnkGeom& g, bool rec, int act, bool saddr);

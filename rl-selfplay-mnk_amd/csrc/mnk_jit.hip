@@ -29,11 +29,13 @@ struct Compiled {
 };
 
 std::mutex g_mu;
-std::map<std::tuple<int, int, int, int, int, int, int>, Compiled> g_cache;  // (device, m, n, k, record, log width, saddr)
+// (device, m, n, k, record, log format, saddr, kind: 0 rollout / 1 replay)
+std::map<std::tuple<int, int, int, int, int, int, int, int>, Compiled> g_cache;
 thread_local char g_jit_err[2048] = "";
 
-// compiles the rollout kernel for this geometry; code object bytes in `code` (no GPU needed for this part)
-bool compile(const MnkGeom& g, bool rec, int act, bool saddr, std::vector<char>& code) {
+// compiles the rollout (kind 0) or the replay kernel (kind 1) for this geometry; code object bytes in `code` (no GPU
+// needed for this part)
+bool compile(const MnkGeom& g, bool rec, int act, bool saddr, std::vector<char>& code, int kind = 0) {
   static const char* program =
       "#include \"mnk_rollout_lane.h\"\n";
   hiprtcProgram prog = nullptr;
@@ -44,9 +46,10 @@ bool compile(const MnkGeom& g, bool rec, int act, bool saddr, std::vector<char>&
   }
   const std::string d_nw = "-DMNK_JIT_NW=" + std::to_string(g.NW), d_cn = "-DMNK_JIT_CN=" + std::to_string(g.n),
                     d_ck = "-DMNK_JIT_CK=" + std::to_string(g.k), d_rec = "-DMNK_JIT_REC=" + std::to_string(rec ? 1 : 0),
-                    d_act = "-DMNK_JIT_ACT=" + std::to_string(act), d_sa = "-DMNK_JIT_SADDR=" + std::to_string(saddr ? 1 : 0);
+                    d_act = "-DMNK_JIT_ACT=" + std::to_string(act), d_sa = "-DMNK_JIT_SADDR=" + std::to_string(saddr ? 1 : 0),
+                    d_kind = "-DMNK_JIT_KIND=" + std::to_string(kind);
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", d_nw.c_str(), d_cn.c_str(),
-                        d_ck.c_str(), d_rec.c_str(), d_act.c_str(), d_sa.c_str()};
+                        d_ck.c_str(), d_rec.c_str(), d_act.c_str(), d_sa.c_str(), d_kind.c_str()};
   const hiprtcResult rc = hiprtcCompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
   if (rc != HIPRTC_SUCCESS) {
     size_t n = 0;
@@ -69,16 +72,16 @@ bool compile(const MnkGeom& g, bool rec, int act, bool saddr, std::vector<char>&
 
 // kernel of this geometry, compiled on first use; nullptr (and mnk_jit_last_error) when that failed -- the caller
 // then stays on the ahead-of-time generic kernel
-hipFunction_t mnk_jit_rollout_function(const MnkGeom& g, bool rec, int act, bool saddr) {
+static hipFunction_t jit_function(const MnkGeom& g, bool rec, int act, bool saddr, int kind) {
   int device = 0;
   if (hipGetDevice(&device) != hipSuccess) return nullptr;  // a code object is loaded into one device's context
   std::lock_guard<std::mutex> lock(g_mu);
-  Compiled& c = g_cache[std::make_tuple(device, g.m, g.n, g.k, rec ? 1 : 0, act, saddr ? 1 : 0)];
+  Compiled& c = g_cache[std::make_tuple(device, g.m, g.n, g.k, rec ? 1 : 0, act, saddr ? 1 : 0, kind)];
   if (c.fn || c.failed) return c.fn;
   std::vector<char> code;
-  if (!compile(g, rec, act, saddr, code)) { c.failed = true; return nullptr; }
+  if (!compile(g, rec, act, saddr, code, kind)) { c.failed = true; return nullptr; }
   if (hipModuleLoadData(&c.module, code.data()) != hipSuccess ||
-      hipModuleGetFunction(&c.fn, c.module, "mnk_jit_rollout") != hipSuccess) {
+      hipModuleGetFunction(&c.fn, c.module, kind ? "mnk_jit_replay" : "mnk_jit_rollout") != hipSuccess) {
     snprintf(g_jit_err, sizeof(g_jit_err), "hipModuleLoadData / hipModuleGetFunction failed: %s",
              hipGetErrorString(hipGetLastError()));
     c.failed = true;
@@ -87,6 +90,22 @@ hipFunction_t mnk_jit_rollout_function(const MnkGeom& g, bool rec, int act, bool
   }
   c.code_bytes = code.size();
   return c.fn;
+}
+
+hipFunction_t mnk_jit_rollout_function(const MnkGeom& g, bool rec, int act, bool saddr) {
+  return jit_function(g, rec, act, saddr, 0);
+}
+
+// the replay of an action log in format `act` (boards of more than 16 register words have no ahead-of-time variant)
+hipFunction_t mnk_jit_replay_function(const MnkGeom& g, bool rec, int act) { return jit_function(g, rec, act, false, 1); }
+
+int mnk_jit_launch_replay(hipFunction_t fn, MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, const void* act_log,
+                          uint64_t* rec_planes, uint32_t* rec_meta, int32_t* err, void* stream) {
+  void* args[] = {&g, &planes, &meta, &N, &T, &act_log, &rec_planes, &rec_meta, &err};
+  const unsigned grid = (unsigned)((N + 63) / 64);
+  if (hipModuleLaunchKernel(fn, grid, 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args, nullptr) != hipSuccess)
+    return mnk_launch_status("replay_actions (run-time specialised)");
+  return MNK_OK;
 }
 
 int mnk_jit_launch_rollout(hipFunction_t fn, MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed,

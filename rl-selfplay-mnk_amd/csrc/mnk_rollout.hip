@@ -14,116 +14,12 @@
 // current four plies are played.
 // ACTB = 3 (MNK_ACT_BITS7): the log is a stream of 7-bit actions; the reader mirrors the writer of mnk_rollout_lane.h --
 // a 64-bit accumulator whose fill level is wave-uniform, one u32 word fetched (ahead) whenever fewer than 28 bits remain.
+// (the body lives in mnk_rollout_lane.h: boards of more than 16 register words get it compiled at run time, mnk_jit.hip)
 template <int NW, int CN, int CK, bool RECORD, int ACTB>
 __global__ void __launch_bounds__(64)
 k_replay_actions(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, const void* act_log,
                  uint64_t* rec_planes, uint32_t* rec_meta, int32_t* err) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  RolloutLane<NW, CN, CK, RECORD> L(g, N, i, rec_planes, rec_meta, nullptr);
-  L.load(planes, meta, i);
-  if constexpr (ACTB == 3) {
-    bool bad7 = false;
-    auto play7 = [&](uint32_t a) {
-      if (a >= (uint32_t)g.C) { bad7 = true; a = 0; }
-      L.ply_action((int)a);
-    };
-    const int quads = (T + 3) >> 2, nwords = (7 * quads + 7) >> 3;
-    const uint32_t* src = (const uint32_t*)act_log + i;
-    uint32_t ahead = nwords ? src[0] : 0u;
-    int w = 1;
-    uint32_t cur = 0, have = 0;  // bits left over from the last word (low-aligned) and their number: 0, 4, ..., 28 (uniform)
-    auto take_word = [&]() -> uint32_t {
-      const uint32_t word = ahead;
-      ahead = src[(int64_t)(w < nwords ? w : nwords - 1) * N];
-      ++w;
-      return word;
-    };
-    auto next_quad = [&]() -> uint32_t {  // 32-bit arithmetic only; seven words per eight quads
-      uint32_t q;
-      if (have == 28u) {
-        q = cur;
-        cur = 0u;
-        have = 0u;
-      } else {
-        const uint32_t word = take_word();
-        q = (cur | (word << have)) & 0x0FFFFFFFu;  // have == 0: cur == 0
-        cur = word >> (28u - have);
-        have += 4u;
-      }
-      return q;
-    };
-    int t = 0;
-    for (; t + 4 <= T; t += 4) {
-      const uint32_t q = next_quad();
-      play7(q & 0x7Fu);
-      play7((q >> 7) & 0x7Fu);
-      play7((q >> 14) & 0x7Fu);
-      play7((q >> 21) & 0x7Fu);
-    }
-    if (t < T) {
-      uint32_t q = next_quad();
-      for (; t < T; ++t, q >>= 7) play7(q & 0x7Fu);
-    }
-    if (bad7) mnk_report(err, MNK_ERR_ACTION_RANGE, i);
-    L.store(planes, meta, i);
-    return;
-  }
-  if constexpr (ACTB == 4) {  // MNK_ACT_U8P1: a word of four low bytes per group, a word of 32 high bits per 32 plies
-    bool bad9 = false;
-    auto play9 = [&](uint32_t a) {
-      if (a >= (uint32_t)g.C) { bad9 = true; a = 0; }
-      L.ply_action((int)a);
-    };
-    const int quads = (T + 3) >> 2, hwords = (T + 31) >> 5;
-    const uint32_t* lo = (const uint32_t*)act_log + i;
-    const uint32_t* hi = lo + (int64_t)quads * N;
-    uint32_t ahead = quads ? lo[0] : 0u;
-    uint32_t hbits = hwords ? hi[0] : 0u;
-    int t = 0;
-    for (int q = 0; t < T; ++q) {
-      const uint32_t word = ahead;
-      ahead = lo[(int64_t)(q + 1 < quads ? q + 1 : q) * N];
-      if (q && (q & 7) == 0) hbits = hi[(int64_t)(q >> 3) * N];  // plies 4q .. 4q+3 are bits (4q .. 4q+3) % 32 of word q / 8
-      const uint32_t h4 = hbits >> (4 * (q & 7));
-      if (t + 4 <= T) {
-        play9((word & 0xFFu) | ((h4 & 1u) << 8));
-        play9(((word >> 8) & 0xFFu) | ((h4 & 2u) << 7));
-        play9(((word >> 16) & 0xFFu) | ((h4 & 4u) << 6));
-        play9((word >> 24) | ((h4 & 8u) << 5));
-        t += 4;
-      } else {
-        for (int j = 0; t < T; ++t, ++j) play9(((word >> (8 * j)) & 0xFFu) | (((h4 >> j) & 1u) << 8));
-      }
-    }
-    if (bad9) mnk_report(err, MNK_ERR_ACTION_RANGE, i);
-    L.store(planes, meta, i);
-    return;
-  }
-  constexpr uint32_t FIELD = ACTB == 1 ? 0xFFu : 0xFFFFu;
-  auto fetch = [&](int q) -> uint64_t {
-    if (ACTB == 1) return (uint64_t)((const uint32_t*)act_log)[(int64_t)q * N + i];
-    return ((const uint64_t*)act_log)[(int64_t)q * N + i];
-  };
-  bool bad = false;
-  auto play = [&](uint32_t a) {
-    if (a >= (uint32_t)g.C) { bad = true; a = 0; }  // a log we did not write: flag it, keep the wave in step
-    L.ply_action((int)a);
-  };
-  const int words = (T + 3) >> 2;
-  uint64_t ahead = words ? fetch(0) : 0;
-  int t = 0;
-  for (int q = 0; t + 4 <= T; ++q, t += 4) {
-    const uint64_t quad = ahead;
-    ahead = fetch(q + 1 < words ? q + 1 : q);
-    play((uint32_t)(quad >> (0 * 8 * ACTB)) & FIELD);
-    play((uint32_t)(quad >> (1 * 8 * ACTB)) & FIELD);
-    play((uint32_t)(quad >> (2 * 8 * ACTB)) & FIELD);
-    play((uint32_t)(quad >> (3 * 8 * ACTB)) & FIELD);
-  }
-  for (uint64_t quad = ahead; t < T; ++t, quad >>= 8 * ACTB) play((uint32_t)quad & FIELD);  // a partly filled last word
-  if (bad) mnk_report(err, MNK_ERR_ACTION_RANGE, i);
-  L.store(planes, meta, i);
+  replay_actions_body<NW, CN, CK, RECORD, ACTB>(g, planes, meta, N, T, act_log, rec_planes, rec_meta, err);
 }
 
 // ================================================================== C ABI
@@ -166,11 +62,16 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   // enough to pay for the ~1 s of compilation: MNK_JIT=1 always, MNK_JIT=0 never, unset = from 2^20 env-steps per
   // launch (4 096 envs x 256 plies).  If the compile fails the generic kernel below still runs.
   if (!pair_geom) {
-    const bool want = cfg.jit >= 0 ? cfg.jit != 0 : (N * (int64_t)T >= (1ll << 20));
+    const bool must = g.NW > 16;  // planes of more than 512 bits: no ahead-of-time kernel (mnk_host.h, MNK_DISPATCH16)
+    const bool want = must || (cfg.jit >= 0 ? cfg.jit != 0 : (N * (int64_t)T >= (1ll << 20)));
     if (want) {
       if (hipFunction_t fn = mnk_jit_rollout_function(g, rec, act_bytes, rec && mnk_rollout_saddr_ok(g, N, T)))
         return mnk_jit_launch_rollout(fn, g, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,
                                       rec ? rec_meta : nullptr, stats, act_log, stream);
+      if (must) {
+        snprintf(g_launch_err, sizeof(g_launch_err), "rollout_random: no kernel for this board: %.200s", mnk_jit_last_error());
+        return MNK_ELAUNCH;
+      }
     }
   }
   // two lanes per env: split by WORDS on the boards where that measured faster (us per 256 plies at 32 768 envs,
@@ -213,7 +114,7 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
     return mnk_launch_status("rollout_random");
   }
 #define MNK_ROLLOUT(REC)                                                                                       \
-  MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NW, CN, CK, REC, 0>), grid, dim3(B), 0, \
+  MNK_DISPATCH16(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NW, CN, CK, REC, 0>), grid, dim3(B), 0, \
                                      (hipStream_t)stream, g, planes, meta, N, T, seed, step0, env_id0,         \
                                      rec_planes, rec_meta, (unsigned long long*)stats, act_log))
   if (rec) MNK_ROLLOUT(true);
@@ -242,14 +143,22 @@ int mnk_replay_actions(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
   if (N == 0 || T == 0) return MNK_OK;
   const int B = 64;
   const dim3 grid((unsigned)((N + B - 1) / B));
+  if (g.NW > 16) {  // planes of more than 512 bits: the run-time specialised kernel is the only one (mnk_host.h)
+    const bool with_rec = rec_planes && rec_meta;
+    if (hipFunction_t fn = mnk_jit_replay_function(g, with_rec, act_bytes))
+      return mnk_jit_launch_replay(fn, g, planes, meta, N, T, act_log, with_rec ? rec_planes : nullptr,
+                                   with_rec ? rec_meta : nullptr, err, stream);
+    snprintf(g_launch_err, sizeof(g_launch_err), "replay_actions: no kernel for this board: %.200s", mnk_jit_last_error());
+    return MNK_ELAUNCH;
+  }
 #define MNK_REPLAY(REC, ACTB)                                                                                       \
-  MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_replay_actions<NW, CN, CK, REC, ACTB>), grid, dim3(B), 0,    \
+  MNK_DISPATCH16(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_replay_actions<NW, CN, CK, REC, ACTB>), grid, dim3(B), 0,    \
                                      (hipStream_t)stream, g, planes, meta, N, T, act_log, REC ? rec_planes : nullptr, \
                                      REC ? rec_meta : nullptr, err))
   const bool rec = rec_planes && rec_meta;
   if (act_bytes == MNK_ACT_U8P1) {
 #define MNK_REPLAY9(REC)                                                                                               \
-  MNK_DISPATCH_LARGE(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_replay_actions<NW, CN, CK, REC, 4>), grid, dim3(B), 0,    \
+  MNK_DISPATCH16_LARGE(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_replay_actions<NW, CN, CK, REC, 4>), grid, dim3(B), 0,    \
                                            (hipStream_t)stream, g, planes, meta, N, T, act_log,                        \
                                            REC ? rec_planes : nullptr, REC ? rec_meta : nullptr, err))
     if (rec) MNK_REPLAY9(true);

@@ -443,14 +443,142 @@ __device__ __forceinline__ void rollout_random_body(const MnkGeom& g, uint64_t* 
               (unsigned long long)lds_stats[threadIdx.x]);
 }
 
+// ------------------------------------------------------------------ replay of an action log (one lane per env)
+// The receiving side of the multi-GPU exchange: a shard's rollout is fully determined by its chunk-start state and its
+// action log, so that is what crosses xGMI; this re-plays the log and rebuilds the full packed records, bit-identical to
+// the sender's.  ACTB = the log format (MNK_ACT_U8 / _U16 / _BITS7 / _U8P1), a template parameter like everything else
+// that shapes the ply loop.
+template <int NW, int CN, int CK, bool RECORD, int ACTB>
+__device__ __forceinline__ void replay_actions_body(const MnkGeom& g, uint64_t* planes, uint32_t* meta, int64_t N, int T,
+                                                    const void* act_log, uint64_t* rec_planes, uint32_t* rec_meta,
+                                                    int32_t* err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  RolloutLane<NW, CN, CK, RECORD> L(g, N, i, rec_planes, rec_meta, nullptr);
+  L.load(planes, meta, i);
+  if constexpr (ACTB == 3) {
+    bool bad7 = false;
+    auto play7 = [&](uint32_t a) {
+      if (a >= (uint32_t)g.C) { bad7 = true; a = 0; }
+      L.ply_action((int)a);
+    };
+    const int quads = (T + 3) >> 2, nwords = (7 * quads + 7) >> 3;
+    const uint32_t* src = (const uint32_t*)act_log + i;
+    uint32_t ahead = nwords ? src[0] : 0u;
+    int w = 1;
+    uint32_t cur = 0, have = 0;  // bits left over from the last word (low-aligned) and their number: 0, 4, ..., 28 (uniform)
+    auto take_word = [&]() -> uint32_t {
+      const uint32_t word = ahead;
+      ahead = src[(int64_t)(w < nwords ? w : nwords - 1) * N];
+      ++w;
+      return word;
+    };
+    auto next_quad = [&]() -> uint32_t {  // 32-bit arithmetic only; seven words per eight quads
+      uint32_t q;
+      if (have == 28u) {
+        q = cur;
+        cur = 0u;
+        have = 0u;
+      } else {
+        const uint32_t word = take_word();
+        q = (cur | (word << have)) & 0x0FFFFFFFu;  // have == 0: cur == 0
+        cur = word >> (28u - have);
+        have += 4u;
+      }
+      return q;
+    };
+    int t = 0;
+    for (; t + 4 <= T; t += 4) {
+      const uint32_t q = next_quad();
+      play7(q & 0x7Fu);
+      play7((q >> 7) & 0x7Fu);
+      play7((q >> 14) & 0x7Fu);
+      play7((q >> 21) & 0x7Fu);
+    }
+    if (t < T) {
+      uint32_t q = next_quad();
+      for (; t < T; ++t, q >>= 7) play7(q & 0x7Fu);
+    }
+    if (bad7) mnk_report(err, MNK_ERR_ACTION_RANGE, i);
+    L.store(planes, meta, i);
+    return;
+  }
+  if constexpr (ACTB == 4) {  // MNK_ACT_U8P1: a word of four low bytes per group, a word of 32 high bits per 32 plies
+    bool bad9 = false;
+    auto play9 = [&](uint32_t a) {
+      if (a >= (uint32_t)g.C) { bad9 = true; a = 0; }
+      L.ply_action((int)a);
+    };
+    const int quads = (T + 3) >> 2, hwords = (T + 31) >> 5;
+    const uint32_t* lo = (const uint32_t*)act_log + i;
+    const uint32_t* hi = lo + (int64_t)quads * N;
+    uint32_t ahead = quads ? lo[0] : 0u;
+    uint32_t hbits = hwords ? hi[0] : 0u;
+    int t = 0;
+    for (int q = 0; t < T; ++q) {
+      const uint32_t word = ahead;
+      ahead = lo[(int64_t)(q + 1 < quads ? q + 1 : q) * N];
+      if (q && (q & 7) == 0) hbits = hi[(int64_t)(q >> 3) * N];  // plies 4q .. 4q+3 are bits (4q .. 4q+3) % 32 of word q / 8
+      const uint32_t h4 = hbits >> (4 * (q & 7));
+      if (t + 4 <= T) {
+        play9((word & 0xFFu) | ((h4 & 1u) << 8));
+        play9(((word >> 8) & 0xFFu) | ((h4 & 2u) << 7));
+        play9(((word >> 16) & 0xFFu) | ((h4 & 4u) << 6));
+        play9((word >> 24) | ((h4 & 8u) << 5));
+        t += 4;
+      } else {
+        for (int j = 0; t < T; ++t, ++j) play9(((word >> (8 * j)) & 0xFFu) | (((h4 >> j) & 1u) << 8));
+      }
+    }
+    if (bad9) mnk_report(err, MNK_ERR_ACTION_RANGE, i);
+    L.store(planes, meta, i);
+    return;
+  }
+  constexpr uint32_t FIELD = ACTB == 1 ? 0xFFu : 0xFFFFu;
+  auto fetch = [&](int q) -> uint64_t {
+    if (ACTB == 1) return (uint64_t)((const uint32_t*)act_log)[(int64_t)q * N + i];
+    return ((const uint64_t*)act_log)[(int64_t)q * N + i];
+  };
+  bool bad = false;
+  auto play = [&](uint32_t a) {
+    if (a >= (uint32_t)g.C) { bad = true; a = 0; }  // a log we did not write: flag it, keep the wave in step
+    L.ply_action((int)a);
+  };
+  const int words = (T + 3) >> 2;
+  uint64_t ahead = words ? fetch(0) : 0;
+  int t = 0;
+  for (int q = 0; t + 4 <= T; ++q, t += 4) {
+    const uint64_t quad = ahead;
+    ahead = fetch(q + 1 < words ? q + 1 : q);
+    play((uint32_t)(quad >> (0 * 8 * ACTB)) & FIELD);
+    play((uint32_t)(quad >> (1 * 8 * ACTB)) & FIELD);
+    play((uint32_t)(quad >> (2 * 8 * ACTB)) & FIELD);
+    play((uint32_t)(quad >> (3 * 8 * ACTB)) & FIELD);
+  }
+  for (uint64_t quad = ahead; t < T; ++t, quad >>= 8 * ACTB) play((uint32_t)quad & FIELD);  // a partly filled last word
+  if (bad) mnk_report(err, MNK_ERR_ACTION_RANGE, i);
+  L.store(planes, meta, i);
+}
+
+
 #ifdef MNK_JIT_NW
 // run-time specialisation (mnk_jit.hip): this board's geometry arrives as macros on the hiprtc command line
+#if !defined(MNK_JIT_KIND) || MNK_JIT_KIND == 0
 extern "C" __global__ void __launch_bounds__(64)
 mnk_jit_rollout(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed, uint64_t step0,
                 int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, unsigned long long* stats, void* act_log) {
   rollout_random_body<MNK_JIT_NW, MNK_JIT_CN, MNK_JIT_CK, MNK_JIT_REC != 0, MNK_JIT_ACT, MNK_JIT_SADDR != 0>(
       g, planes, meta, N, T, seed, step0, env_id0, rec_planes, rec_meta, stats, act_log);
 }
+#else
+// MNK_JIT_KIND == 1: the replay of an action log in format MNK_JIT_ACT
+extern "C" __global__ void __launch_bounds__(64)
+mnk_jit_replay(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, const void* act_log, uint64_t* rec_planes,
+               uint32_t* rec_meta, int32_t* err) {
+  replay_actions_body<MNK_JIT_NW, MNK_JIT_CN, MNK_JIT_CK, MNK_JIT_REC != 0, MNK_JIT_ACT>(g, planes, meta, N, T, act_log,
+                                                                                         rec_planes, rec_meta, err);
+}
+#endif
 #else
 template <int NW, int CN, int CK, bool RECORD, int ACT, bool SADDR = false>
 __global__ void __launch_bounds__(64)

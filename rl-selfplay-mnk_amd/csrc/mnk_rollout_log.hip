@@ -38,12 +38,12 @@ void mnk_launch_rollout_log(const MnkGeom& g, uint64_t* planes, uint32_t* meta, 
     return;
   }
 #define MNK_ROLLOUT(REC, ACTB)                                                                                   \
-  MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NW, CN, CK, REC, ACTB>), grid, dim3(B), 0, \
+  MNK_DISPATCH16(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NW, CN, CK, REC, ACTB>), grid, dim3(B), 0, \
                                      (hipStream_t)stream, g, planes, meta, N, T, seed, step0, env_id0,           \
                                      rec_planes, rec_meta, (unsigned long long*)stats, act_log))
   if (act_bytes == MNK_ACT_U8P1) {  // boards of more than 256 cells: 19x19 and the generic 16-word form
 #define MNK_ROLLOUT9(REC)                                                                                          \
-  MNK_DISPATCH_LARGE(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NW, CN, CK, REC, 4>), grid, dim3(B), 0, \
+  MNK_DISPATCH16_LARGE(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rollout_random<NW, CN, CK, REC, 4>), grid, dim3(B), 0, \
                                            (hipStream_t)stream, g, planes, meta, N, T, seed, step0, env_id0,       \
                                            rec_planes, rec_meta, (unsigned long long*)stats, act_log))
     if (rec) MNK_ROLLOUT9(true);

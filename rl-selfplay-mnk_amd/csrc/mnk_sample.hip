@@ -92,7 +92,8 @@ void dispatch_sample(const void* logits, const uint8_t* mask, int64_t N, int C, 
   else if (C <= 32) MNK_SAMPLE(4, 8, false);
   else if (C <= 96) MNK_SAMPLE(8, 12, false);
   else if (C <= 256) MNK_SAMPLE(16, 16, false);
-  else MNK_SAMPLE(32, 16, false);                // up to 512 cells (22x22)
+  else if (C <= 512) MNK_SAMPLE(32, 16, false);  // up to 512 cells (22x22)
+  else MNK_SAMPLE(32, 32, false);                // up to 1 024 cells (25x25, 31x31)
 #undef MNK_SAMPLE_SHAPE
 #undef MNK_SAMPLE
 }
@@ -112,7 +113,7 @@ int mnk_launch_sample(const MnkSample& sa, int64_t N, int C, hipStream_t s) {
 extern "C" int mnk_sample_logits(const void* logits, int logits_dtype, const uint8_t* mask, int64_t N, int C,
                                  uint64_t seed, const uint64_t* seed_dev, uint64_t step, const uint64_t* step_dev,
                                  int64_t env_id0, int deterministic, int64_t* actions, float* logp, void* stream) {
-  if (!mask || !actions || N < 0 || C < 1 || C > 512) return MNK_EINVAL;
+  if (!mask || !actions || N < 0 || C < 1 || C > 1024) return MNK_EINVAL;
   if (logits_dtype != MNK_LOGITS_F32 && logits_dtype != MNK_LOGITS_BF16) return MNK_EINVAL;
   if (N == 0) return MNK_OK;
   if (N > 0x7fffffffLL) return MNK_EINVAL;

@@ -5,7 +5,7 @@
 #include "mnk_selfplay_kernels.h"
 
 inline int mnk_sample_args_ok(const MnkSample& sa, int64_t N, int C) {
-  if (!sa.mask || !sa.actions || C < 1 || C > 512 || N > 0x7fffffffLL) return MNK_EINVAL;
+  if (!sa.mask || !sa.actions || C < 1 || C > 1024 || N > 0x7fffffffLL) return MNK_EINVAL;
   if (sa.logits_dtype != MNK_LOGITS_F32 && sa.logits_dtype != MNK_LOGITS_BF16) return MNK_EINVAL;
   return MNK_OK;
 }

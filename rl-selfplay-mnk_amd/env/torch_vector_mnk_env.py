@@ -171,7 +171,7 @@ class TorchVectorMnkEnv:
         mnk_hip.load()
         if not mnk_hip.geometry_supported(m, n, k):
             raise ValueError(f"board {m}x{n} (k={k}) is outside the packed layout's range "
-                             "(2 <= n <= 61, m*(n+1) <= 512 bits)")
+                             "(2 <= n <= 61, m*(n+1) <= 1024 bits)")
         if dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
         elif dev.index != torch.cuda.current_device():

@@ -142,17 +142,18 @@ ACT_U8, ACT_U16, ACT_BITS7, ACT_U8P1 = 1, 2, 3, 4  # include/mnk_hip.h MNK_ACT_*
 
 def action_log_format(num_actions: int, compact: bool = True) -> int:
     """The most compact log format a board of ``num_actions`` cells allows: 7 bits per action up to 128 cells, one byte
-    up to 256, a byte and a bit beyond (without ``compact``: one byte up to 256 cells, two bytes beyond -- round 2's)."""
+    up to 256, a byte and a bit up to 512, two bytes beyond (without ``compact``: one byte up to 256 cells, two bytes
+    beyond -- round 2's)."""
     if compact and num_actions <= 128:
         return ACT_BITS7
     if num_actions <= 256:
         return ACT_U8
-    return ACT_U8P1 if compact else ACT_U16
+    return ACT_U8P1 if compact and num_actions <= 512 else ACT_U16
 
 
 def action_log_fits(fmt: int, num_actions: int) -> bool:
     return fmt == ACT_U16 or (fmt == ACT_U8 and num_actions <= 256) or (fmt == ACT_BITS7 and num_actions <= 128) or \
-        (fmt == ACT_U8P1 and num_actions > 256)
+        (fmt == ACT_U8P1 and 256 < num_actions <= 512)
 
 
 def action_log_words(fmt: int, steps: int) -> int:

@@ -55,8 +55,11 @@ def test_geometry_queries_need_no_gpu(lib):
     assert [lib.state_words(*s) for s in [(3, 3), (9, 9), (13, 13), (19, 19)]] == [1, 2, 3, 6]
     assert lib.geometry_supported(9, 9, 5) and lib.geometry_supported(19, 19, 5) and lib.geometry_supported(22, 22, 5)
     assert not lib.geometry_supported(3, 3, 4)      # k larger than the board
-    assert not lib.geometry_supported(30, 30, 5)    # beyond 512 bits per plane
-    assert lib.state_words(30, 30) == 0
+    assert lib.geometry_supported(25, 25, 5) and lib.geometry_supported(31, 31, 6) and lib.geometry_supported(16, 61, 5)
+    assert lib.state_words(25, 25) == 11 and lib.record_words(25, 25) == 21 and lib.state_words(31, 31) == 16
+    assert not lib.geometry_supported(32, 32, 5)    # beyond 1 024 bits per plane
+    assert not lib.geometry_supported(9, 62, 5)     # rows of more than 61 cells
+    assert lib.state_words(32, 32) == 0
 
 
 def test_argument_errors_are_reported_not_crashed(lib):
@@ -85,7 +88,7 @@ def test_rollout_kernel_specialises_at_run_time_without_a_gpu(lib):
     for (m, n, k, rec, act) in [(12, 12, 5, 1, 0), (7, 9, 7, 0, 1), (22, 22, 10, 1, 2), (11, 11, 5, 1, 3), (22, 22, 10, 1, 4)]:
         size = handle.mnk_jit_compile_rollout(m, n, k, rec, act)
         assert size > 4096, (handle.mnk_jit_last_error() or b"").decode()
-    assert handle.mnk_jit_compile_rollout(30, 30, 5, 1, 0) == -2   # MNK_EGEOM: beyond the packed layout
+    assert handle.mnk_jit_compile_rollout(40, 40, 5, 1, 0) == -2   # MNK_EGEOM: beyond the packed layout
     assert handle.mnk_jit_compile_rollout(13, 13, 5, 1, 3) == -1   # MNK_EINVAL: 169 cells do not fit the 7-bit log
     assert handle.mnk_jit_compile_rollout(9, 9, 5, 1, 4) == -1     # MNK_EINVAL: the byte + bit log is for boards above 256 cells
     assert handle.mnk_jit_compile_rollout(9, 9, 5, 1, 5) == -1     # MNK_EINVAL: no such log format

@@ -49,6 +49,9 @@ def _seeds(default):
     return range(default)
 
 
+_MAX_WRAPPER_STEPS = [10 ** 9]  # (the large-board runs bound the 3 * cells steps of the wrapper fuzzer)
+
+
 def _shape(rng):
     while True:
         m, n = int(rng.integers(2, 20)), int(rng.integers(2, 20))
@@ -181,7 +184,7 @@ def test_wrapper_fuzz(hip, seed):
     o1, _ = wrap.reset()
     o2, _ = ora.reset()
     _same_obs(o1, o2, "reset")
-    for t in range(3 * c):
+    for t in range(min(3 * c, _MAX_WRAPPER_STEPS[0])):
         where = f"seed {seed} {m}x{n}x{k} N={nenv} step {t}"
         mask = o2["action_mask"].numpy()
         acts = np.array([rng.choice(np.nonzero(row)[0]) if rng.random() > 0.05 else rng.integers(0, c) for row in mask])
@@ -287,3 +290,29 @@ def test_rollout_and_log_fuzz(hip, seed):
         else:
             os.environ["MNK_JIT"] = saved
         hip.lib.reload_config()
+
+
+# ----------------------------------------------------------------------------- round 4: boards of up to 1 024 bits
+LARGE = [(25, 25, 5), (31, 31, 6), (16, 61, 5), (23, 40, 7), (22, 23, 10)]
+
+
+@pytest.mark.parametrize("shape", LARGE)
+def test_large_boards_through_the_fuzzers(hip, shape, monkeypatch):
+    """The reference takes any board (env/torch_vector_mnk_env.py:9).  Round 4 lifted the packed layout from 512 to 1 024
+    bits per plane (16 u64 words: 25x25, 31x31, rows of up to 61 cells): the three differential fuzzers on boards beyond
+    the old limit -- every env operation, the wrapper (a third of its steps through the folded draw), the rollout with
+    its log formats (two bytes per action above 512 cells), replays and the one-launch step, generic and run-time
+    specialised kernels -- against the oracle."""
+    import sys
+
+    me = sys.modules[__name__]
+    monkeypatch.setattr(me, "_shape", lambda rng: shape)
+    _MAX_WRAPPER_STEPS[0] = 260
+    try:
+        base = 500 + 10 * LARGE.index(shape)
+        for seed in (base, base + 1):
+            test_env_fuzz(hip, seed)
+            test_rollout_and_log_fuzz(hip, seed)
+        test_wrapper_fuzz(hip, base)
+    finally:
+        _MAX_WRAPPER_STEPS[0] = 10 ** 9

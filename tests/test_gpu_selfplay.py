@@ -995,7 +995,7 @@ def test_bf16_logits_are_sampled_without_an_f32_copy(hip, golden_dir):
     assert torch.equal(a1, torch.argmax(ref.logits, dim=1)) and torch.allclose(l1, ref.log_prob(a1), atol=1e-5, rtol=0)
 
 
-@pytest.mark.parametrize("m,n", [(3, 3), (4, 6), (7, 9), (9, 9), (10, 10), (13, 13), (15, 15), (19, 19), (22, 22)])
+@pytest.mark.parametrize("m,n", [(3, 3), (4, 6), (7, 9), (9, 9), (10, 10), (13, 13), (15, 15), (19, 19), (22, 22), (25, 25), (31, 31)])
 def test_sampler_all_row_widths(hip, m, n):
     """every (lanes per row, cells per lane) variant of k_sample_logits, ragged last workgroup included: argmax,
     log-prob and legality of the draws against torch's masked Categorical"""
