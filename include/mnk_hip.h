@@ -305,6 +305,15 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
  * mnk_jit_compile_rollout only compiles (no GPU needed): code object bytes, or a negative status with the
  * compiler's log in mnk_jit_last_error(). */
 int64_t mnk_jit_compile_rollout(int m, int n, int k, int record, int act_bytes);
+/* Round 4: two more kernels exist as run-time specialisations -- the replay of an action log (mnk_replay_actions) and the
+ * two-lanes-per-env form of the rollout (batches of up to 32 768 envs).  Boards whose planes take more than 512 bits
+ * (25x25, 31x31 ...) have NO ahead-of-time rollout / replay kernel: theirs are always compiled at run time (~2 s).
+ * mnk_jit_compile_kernel is mnk_jit_compile_rollout for any of the three (kind below; act_bytes of a replay = the log
+ * format it reads). */
+#define MNK_JIT_ROLLOUT 0
+#define MNK_JIT_REPLAY 1
+#define MNK_JIT_ROLLOUT_PAIR 2
+int64_t mnk_jit_compile_kernel(int m, int n, int k, int record, int act_bytes, int kind);
 const char* mnk_jit_last_error(void);
 
 /* The multi-GPU exchange format.  A shard's rollout is a pure function of its chunk-start state and

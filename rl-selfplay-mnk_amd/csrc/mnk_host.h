@@ -239,6 +239,10 @@ void mnk_launch_rollout_ws(const MnkGeom& g, int ws, uint64_t* planes, uint32_t*
     else MNK_CASE(16, 0, 0, __VA_ARGS__)                                                 \
   } while (0)
 hipFunction_t mnk_jit_replay_function(const MnkGeom& g, bool rec, int act);
+hipFunction_t mnk_jit_rollout_pair_function(const MnkGeom& g, bool rec, int act);
+int mnk_jit_launch_rollout_lanes(hipFunction_t fn, MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed,
+                                 uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
+                                 void* act_log, void* stream, int lanes_per_env);
 int mnk_jit_launch_replay(hipFunction_t fn, MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, const void* act_log,
                           uint64_t* rec_planes, uint32_t* rec_meta, int32_t* err, void* stream);
 

@@ -81,7 +81,7 @@ static hipFunction_t jit_function(const MnkGeom& g, bool rec, int act, bool sadd
   std::vector<char> code;
   if (!compile(g, rec, act, saddr, code, kind)) { c.failed = true; return nullptr; }
   if (hipModuleLoadData(&c.module, code.data()) != hipSuccess ||
-      hipModuleGetFunction(&c.fn, c.module, kind ? "mnk_jit_replay" : "mnk_jit_rollout") != hipSuccess) {
+      hipModuleGetFunction(&c.fn, c.module, kind == 1 ? "mnk_jit_replay" : (kind == 2 ? "mnk_jit_rollout_pair" : "mnk_jit_rollout")) != hipSuccess) {
     snprintf(g_jit_err, sizeof(g_jit_err), "hipModuleLoadData / hipModuleGetFunction failed: %s",
              hipGetErrorString(hipGetLastError()));
     c.failed = true;
@@ -95,6 +95,9 @@ static hipFunction_t jit_function(const MnkGeom& g, bool rec, int act, bool sadd
 hipFunction_t mnk_jit_rollout_function(const MnkGeom& g, bool rec, int act, bool saddr) {
   return jit_function(g, rec, act, saddr, 0);
 }
+
+// the two-lanes-per-env form of the rollout (batches of up to 32 768 envs; byte / 16-bit logs or none)
+hipFunction_t mnk_jit_rollout_pair_function(const MnkGeom& g, bool rec, int act) { return jit_function(g, rec, act, false, 2); }
 
 // the replay of an action log in format `act` (boards of more than 16 register words have no ahead-of-time variant)
 hipFunction_t mnk_jit_replay_function(const MnkGeom& g, bool rec, int act) { return jit_function(g, rec, act, false, 1); }
@@ -111,8 +114,17 @@ int mnk_jit_launch_replay(hipFunction_t fn, MnkGeom g, uint64_t* planes, uint32_
 int mnk_jit_launch_rollout(hipFunction_t fn, MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed,
                            uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
                            void* act_log, void* stream) {
+  return mnk_jit_launch_rollout_lanes(fn, g, planes, meta, N, T, seed, step0, env_id0, rec_planes, rec_meta, stats, act_log,
+                                      stream, 1);
+}
+
+// lanes_per_env: 1 (64 envs per workgroup) or 2 (the pair form: 32 envs per workgroup)
+int mnk_jit_launch_rollout_lanes(hipFunction_t fn, MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed,
+                                 uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
+                                 void* act_log, void* stream, int lanes_per_env) {
   void* args[] = {&g, &planes, &meta, &N, &T, &seed, &step0, &env_id0, &rec_planes, &rec_meta, &stats, &act_log};
-  const unsigned grid = (unsigned)((N + 63) / 64);
+  const int per_group = 64 / lanes_per_env;
+  const unsigned grid = (unsigned)((N + per_group - 1) / per_group);
   if (hipModuleLaunchKernel(fn, grid, 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args, nullptr) != hipSuccess)
     return mnk_launch_status("rollout_random (run-time specialised)");
   return MNK_OK;
@@ -131,6 +143,20 @@ int64_t mnk_jit_compile_rollout(int m, int n, int k, int record, int act_bytes) 
   if (!mnk_act_format_ok(act_bytes, g.C)) return MNK_EINVAL;
   std::vector<char> code;
   if (!compile(g, record != 0, act_bytes, record != 0, code)) return MNK_ELAUNCH;  // the form a 65 536-env launch uses
+  return (int64_t)code.size();
+}
+
+// the same for any of the run-time specialised kernels: kind MNK_JIT_ROLLOUT (one lane per env), MNK_JIT_REPLAY
+// (mnk_replay_actions; act_bytes = the log format it reads) or MNK_JIT_ROLLOUT_PAIR (two lanes per env)
+int64_t mnk_jit_compile_kernel(int m, int n, int k, int record, int act_bytes, int kind) {
+  MnkGeom g;
+  const int rc = mnk_check_geom(m, n, k, &g);
+  if (rc != MNK_OK) return rc;
+  if (kind < MNK_JIT_ROLLOUT || kind > MNK_JIT_ROLLOUT_PAIR || !mnk_act_format_ok(act_bytes, g.C)) return MNK_EINVAL;
+  if (kind == MNK_JIT_REPLAY && act_bytes == 0) return MNK_EINVAL;
+  if (kind == MNK_JIT_ROLLOUT_PAIR && (act_bytes == MNK_ACT_BITS7 || act_bytes == MNK_ACT_U8P1)) return MNK_EINVAL;
+  std::vector<char> code;
+  if (!compile(g, record != 0, act_bytes, kind == MNK_JIT_ROLLOUT && record != 0, code, kind)) return MNK_ELAUNCH;
   return (int64_t)code.size();
 }
 

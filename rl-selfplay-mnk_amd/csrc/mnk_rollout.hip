@@ -65,6 +65,13 @@ int mnk_rollout_random(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n
     const bool must = g.NW > 16;  // planes of more than 512 bits: no ahead-of-time kernel (mnk_host.h, MNK_DISPATCH16)
     const bool want = must || (cfg.jit >= 0 ? cfg.jit != 0 : (N * (int64_t)T >= (1ll << 20)));
     if (want) {
+      // two lanes per env for small batches, like the compile-time boards (same threshold, same results): round 4
+      const bool pair_ok = w_fits && act_bytes != MNK_ACT_BITS7 && act_bytes != MNK_ACT_U8P1 && cfg.form != MNK_FORM_LANE &&
+                           (pair_override >= 0 ? pair_override != 0 : N <= 32768);
+      if (pair_ok)
+        if (hipFunction_t fn = mnk_jit_rollout_pair_function(g, rec, act_bytes))
+          return mnk_jit_launch_rollout_lanes(fn, g, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,
+                                              rec ? rec_meta : nullptr, stats, act_log, stream, 2);
       if (hipFunction_t fn = mnk_jit_rollout_function(g, rec, act_bytes, rec && mnk_rollout_saddr_ok(g, N, T)))
         return mnk_jit_launch_rollout(fn, g, planes, meta, N, T, seed, step0, env_id0, rec ? rec_planes : nullptr,
                                       rec ? rec_meta : nullptr, stats, act_log, stream);

@@ -443,6 +443,72 @@ __device__ __forceinline__ void rollout_random_body(const MnkGeom& g, uint64_t* 
               (unsigned long long)lds_stats[threadIdx.x]);
 }
 
+// ------------------------------------------------------------------ two lanes per env (scan directions split)
+// the T plies of one lane pair (FAST: see mnk_rollout_lane.h -- every game of the wave consistent)
+template <bool FAST, typename Lane>
+__device__ __forceinline__ void pair_plies(Lane& L, int T, uint64_t seed, uint64_t step0, uint64_t env, uint32_t role) {
+  int t = 0;
+  uint64_t step = step0;
+  // unshared Philox until the step counter sits on a multiple of 8 (two blocks)
+  for (; t < T && (step & 7); ++t, ++step)
+    L.template ply<FAST>(mnk_rand_u32(seed, env, step, MNK_STREAM_MOVE), (int)(step & 3));
+  for (; t + 8 <= T; t += 8, step += 8) {
+    // lane `role` computes block (step/4 + role); the partner's four words arrive by DPP
+    const Philox4 mine = mnk_rng_block(seed, env, (step >> 2) + role, MNK_STREAM_MOVE);
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t other = pair_swap(mine.v[j]);
+      lo[j] = role ? other : mine.v[j];  // block step/4
+      hi[j] = role ? mine.v[j] : other;  // block step/4 + 1
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) L.template ply<FAST>(lo[j], j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) L.template ply<FAST>(hi[j], j);
+  }
+  for (; t < T; ++t, ++step) L.template ply<FAST>(mnk_rand_u32(seed, env, step, MNK_STREAM_MOVE), (int)(step & 3));
+}
+
+template <int NW, int CN, int CK, bool RECORD, int ACT>
+__device__ __forceinline__ void rollout_random_pair_body(const MnkGeom& g, uint64_t* planes, uint32_t* meta, int64_t N, int T,
+                                                         uint64_t seed, uint64_t step0, int64_t env_id0, uint64_t* rec_planes,
+                                                         uint32_t* rec_meta, unsigned long long* stats, void* act_log) {
+  __shared__ unsigned int lds_stats[MNK_STATS_COUNTERS];
+  if (threadIdx.x < MNK_STATS_COUNTERS) lds_stats[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t role = threadIdx.x & 1u;
+  const int64_t i = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 1);  // env of this lane pair
+  if (i < N) {
+    RolloutLane<NW, CN, CK, RECORD, ACT, true> L(g, N, i, rec_planes, rec_meta, act_log, role);
+    L.load(planes, meta, i);
+    const uint64_t env = (uint64_t)(env_id0 + i);
+    // both lanes of a pair hold the whole board: the consistency test of the one-lane form applies as it is.  Small
+    // boards only (what the launcher uses this form for: 3x3 and 9x9); the larger ones keep the one general loop.
+    constexpr bool TRY_FAST = NW <= 3;
+    if (TRY_FAST && __builtin_amdgcn_ballot_w64(!L.consistent()) == 0) {
+      pair_plies<true>(L, T, seed, step0, env, role);
+      L.finish_fast();
+    } else {
+      pair_plies<false>(L, T, seed, step0, env, role);
+    }
+    if (ACT && (T & 3)) L.log_flush();
+    L.store(planes, meta, i);  // lane `role` stores plane `role`; the meta word is written by both
+    if (stats && role == 0) {
+      const uint32_t len_sum = L.moves_in + (uint32_t)T - L.moves;
+      if (L.acc_done) atomicAdd(&lds_stats[0], L.acc_done);
+      if (L.acc_win - L.acc_white) atomicAdd(&lds_stats[1], L.acc_win - L.acc_white);
+      if (L.acc_white) atomicAdd(&lds_stats[2], L.acc_white);
+      if (L.acc_done - L.acc_win) atomicAdd(&lds_stats[3], L.acc_done - L.acc_win);
+      if (len_sum) atomicAdd(&lds_stats[4], len_sum);
+    }
+  }
+  __syncthreads();
+  if (stats && threadIdx.x < MNK_STATS_COUNTERS && lds_stats[threadIdx.x])
+    atomicAdd(&stats[(size_t)(blockIdx.x % MNK_STATS_REPLICAS) * MNK_STATS_STRIDE + threadIdx.x],
+              (unsigned long long)lds_stats[threadIdx.x]);
+}
+
 // ------------------------------------------------------------------ replay of an action log (one lane per env)
 // The receiving side of the multi-GPU exchange: a shard's rollout is fully determined by its chunk-start state and its
 // action log, so that is what crosses xGMI; this re-plays the log and rebuilds the full packed records, bit-identical to
@@ -568,6 +634,14 @@ extern "C" __global__ void __launch_bounds__(64)
 mnk_jit_rollout(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed, uint64_t step0,
                 int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, unsigned long long* stats, void* act_log) {
   rollout_random_body<MNK_JIT_NW, MNK_JIT_CN, MNK_JIT_CK, MNK_JIT_REC != 0, MNK_JIT_ACT, MNK_JIT_SADDR != 0>(
+      g, planes, meta, N, T, seed, step0, env_id0, rec_planes, rec_meta, stats, act_log);
+}
+#elif MNK_JIT_KIND == 2
+// the two-lanes-per-env form (scan directions split): 32 envs per wave, for batches of up to 32 768 envs
+extern "C" __global__ void __launch_bounds__(64)
+mnk_jit_rollout_pair(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed, uint64_t step0,
+                     int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, unsigned long long* stats, void* act_log) {
+  rollout_random_pair_body<MNK_JIT_NW, MNK_JIT_CN, MNK_JIT_CK, MNK_JIT_REC != 0, MNK_JIT_ACT>(
       g, planes, meta, N, T, seed, step0, env_id0, rec_planes, rec_meta, stats, act_log);
 }
 #else

@@ -70,6 +70,7 @@ SIGNATURES = {
     "mnk_gather_obs": [_vp, _i64, _i64, _i, _i, _vp, _i64, _vp, _i, _vp, _i, _vp, _vp],
     "mnk_gae": [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _vp, _vp, _vp],
     "mnk_jit_compile_rollout": [_i, _i, _i, _i, _i],
+    "mnk_jit_compile_kernel": [_i, _i, _i, _i, _i, _i],
     "mnk_jit_last_error": [],
     "mnk_comm_unique_id": [_vp],
     "mnk_comm_init": [_vp, _vp, _i, _i],
@@ -113,7 +114,7 @@ def load():
         fn.argtypes = argtypes
         if name in ("mnk_last_launch_error", "mnk_comm_last_error", "mnk_jit_last_error"):
             fn.restype = ctypes.c_char_p
-        elif name == "mnk_jit_compile_rollout":
+        elif name in ("mnk_jit_compile_rollout", "mnk_jit_compile_kernel"):
             fn.restype = ctypes.c_int64
         else:
             fn.restype = ctypes.c_int

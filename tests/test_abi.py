@@ -93,6 +93,18 @@ def test_rollout_kernel_specialises_at_run_time_without_a_gpu(lib):
     assert handle.mnk_jit_compile_rollout(9, 9, 5, 1, 4) == -1     # MNK_EINVAL: the byte + bit log is for boards above 256 cells
     assert handle.mnk_jit_compile_rollout(9, 9, 5, 1, 5) == -1     # MNK_EINVAL: no such log format
     assert [handle.mnk_action_log_words(f, 256) for f in (1, 2, 3, 4, 5)] == [64, 128, 56, 72, 0]
+    # round 4: the replay kernel and the two-lanes-per-env rollout exist as run-time specialisations too, and boards of
+    # more than 512 bits per plane (25x25, 31x31, rows of 61 cells) have no other rollout / replay kernel
+    ROLLOUT, REPLAY, PAIR = 0, 1, 2
+    for (m, n, k, rec, act, kind) in [(12, 12, 5, 1, 0, PAIR), (7, 9, 7, 1, 1, PAIR), (12, 12, 5, 1, 1, REPLAY),
+                                      (25, 25, 5, 1, 2, ROLLOUT), (25, 25, 5, 1, 2, REPLAY), (31, 31, 6, 0, 2, REPLAY),
+                                      (22, 23, 10, 1, 4, REPLAY), (16, 61, 5, 1, 0, PAIR)]:
+        size = handle.mnk_jit_compile_kernel(m, n, k, rec, act, kind)
+        assert size > 4096, (m, n, k, kind, (handle.mnk_jit_last_error() or b"").decode())
+    assert handle.mnk_jit_compile_kernel(12, 12, 5, 1, 0, REPLAY) == -1  # a replay reads a log
+    assert handle.mnk_jit_compile_kernel(11, 11, 5, 1, 3, PAIR) == -1    # the 7-bit stream exists in the one-lane form only
+    assert handle.mnk_jit_compile_kernel(25, 25, 5, 1, 4, ROLLOUT) == -1 # 625 cells: two bytes per action
+    assert handle.mnk_jit_compile_kernel(12, 12, 5, 1, 0, 3) == -1
 
 
 def test_header_is_plain_c(tmp_path):

@@ -243,7 +243,12 @@ def test_rollout_and_log_fuzz(hip, seed):
     fmts = [f for f in (hip.rollout.ACT_U16, hip.rollout.ACT_U8, hip.rollout.ACT_BITS7, hip.rollout.ACT_U8P1)
             if hip.rollout.action_log_fits(f, c)]
     saved = os.environ.get("MNK_JIT")
+    saved_pair = os.environ.get("MNK_ROLLOUT_PAIR")
     os.environ["MNK_JIT"] = str(seed % 2)  # both kernels for boards without a built-in variant
+    # ... and of the run-time specialised ones both forms: one lane per env, two lanes per env (round 4), the launcher's choice
+    os.environ.pop("MNK_ROLLOUT_PAIR", None)
+    if (seed // 2) % 3:
+        os.environ["MNK_ROLLOUT_PAIR"] = str((seed // 2) % 3 - 1)
     hip.lib.reload_config()
     try:
         env, ora = hip.Env(m, n, k, nenv, device=DEV), OracleVectorEnv(m, n, k, nenv)
@@ -289,6 +294,10 @@ def test_rollout_and_log_fuzz(hip, seed):
             os.environ.pop("MNK_JIT", None)
         else:
             os.environ["MNK_JIT"] = saved
+        if saved_pair is None:
+            os.environ.pop("MNK_ROLLOUT_PAIR", None)
+        else:
+            os.environ["MNK_ROLLOUT_PAIR"] = saved_pair
         hip.lib.reload_config()
 
 

@@ -158,7 +158,36 @@ def gae_depth(nenv=65536, T=256):
     mnk_hip.reload_config()
 
 
+def pair_jit(*boards):
+    """the run-time specialised rollout kernel of boards without a built-in variant: one lane per env against two lanes per
+    env (MNK_ROLLOUT_PAIR=0 / 1), us per 256 plies by batch size"""
+    boards = boards or ("12x12x5", "11x11x5", "7x9x7", "10x10x5", "25x25x5")
+    os.environ["MNK_JIT"] = "1"
+    for board in boards:
+        m, n, k = (int(v) for v in board.split("x"))
+        for nenv in (8192, 16384, 32768, 49152):
+            row = {}
+            for pair in ("0", "1"):
+                os.environ["MNK_ROLLOUT_PAIR"] = pair
+                mnk_hip.reload_config()
+                env = TorchVectorMnkEnv(m, n, k, nenv, device=DEV)
+                roll = RandomRollout(env, seed=1)
+                rec = roll.alloc(256)
+                for _ in range(6):
+                    roll.run(256, out=rec)
+                row[pair] = timeit(lambda: roll.run(256, out=rec), reps=20, warm=3)
+            rows = mnk_hip.record_words(m, n)
+            print(f"{board:9s} x {nenv:6d} envs: one lane {row['0']:7.1f} us  two lanes {row['1']:7.1f} us  x{row['0'] / row['1']:.2f}   "
+                  f"({nenv * 256 / min(row.values()) * 1e6:.3e} env-steps/s, {nenv * 256 * (8 * rows + 4) / min(row.values()) / 1e3:.0f} GB/s)",
+                  flush=True)
+    os.environ.pop("MNK_ROLLOUT_PAIR", None)
+    os.environ.pop("MNK_JIT", None)
+    mnk_hip.reload_config()
+
+
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "fused"
-    args = [int(v) for v in sys.argv[2:]]
-    {"fused": fused, "cadence": cadence, "gae": gae_depth}[mode](*args)
+    if mode == "pairjit":
+        pair_jit(*sys.argv[2:])
+        sys.exit(0)
+    {"fused": fused, "cadence": cadence, "gae": gae_depth}[mode](*[int(v) for v in sys.argv[2:]])
