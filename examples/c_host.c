@@ -6,6 +6,8 @@
  *   (A) mnk_rollout_random      T plies per env in one launch, packed records + statistics;
  *   (B) mnk_step_random         the same T plies as T launches (BASELINE config 2 in one launch per ply),
  *                               rewards / dones / legal mask per ply;
+ *   (C) mnk_selfplay_step_random_logits   (ABI v5) self-play agent-steps of the wrapper (src/selfplay/torch_self_play_wrapper.py:
+ *                               32-67) with the agent's masked draw folded into the step kernel: one launch per agent-step;
  * and a check that (A) and (B) leave the same state and count the same finished games.
  * Prints one line of key=value pairs; tests/test_gpu_c_host.py compares it with the Python binding's results.
  *
@@ -136,6 +138,65 @@ int main(int argc, char** argv) {
   HIP_OK(hipMemcpyAsync(h_stats, stats, stats_words * 8, hipMemcpyDeviceToHost, stream));
   HIP_OK(hipStreamSynchronize(stream));
 
+  /* (C) ABI v5: self-play agent-steps with the masked draw folded into the step kernel -- the uniformly random agent
+   * (logits == NULL: the draw reads the mask only) against the uniformly random opponent, ONE launch per agent-step:
+   * draw + log-probability + agent ply + opponent reply + zero-sum merge + the legal mask of the next position.
+   * The first call finds every env pending and resets it (TorchSelfPlayWrapper.reset). */
+  const int S = T < 24 ? T : 24;
+  uint64_t* planes_c;
+  uint32_t* meta_c;
+  uint8_t *pending, *terminated, *mask_in, *mask_out;
+  int64_t *agent_side, *actions;
+  float *sp_rewards, *logp;
+  HIP_OK(hipMalloc((void**)&planes_c, plane_words * 8));
+  HIP_OK(hipMalloc((void**)&meta_c, (size_t)N * 4));
+  HIP_OK(hipMalloc((void**)&pending, (size_t)N));
+  HIP_OK(hipMalloc((void**)&terminated, (size_t)N));
+  HIP_OK(hipMalloc((void**)&mask_in, (size_t)N * C));
+  HIP_OK(hipMalloc((void**)&mask_out, (size_t)N * C));
+  HIP_OK(hipMalloc((void**)&agent_side, (size_t)N * 8));
+  HIP_OK(hipMalloc((void**)&actions, (size_t)N * 8));
+  HIP_OK(hipMalloc((void**)&sp_rewards, (size_t)N * 4));
+  HIP_OK(hipMalloc((void**)&logp, (size_t)N * 4));
+  MNK_OK_(mnk_reset_all(planes_c, meta_c, N, W, stream));
+  HIP_OK(hipMemsetAsync(pending, 1, (size_t)N, stream));
+  HIP_OK(hipMemsetAsync(mask_in, 1, (size_t)N * C, stream));
+  HIP_OK(hipMemsetAsync(agent_side, 0, (size_t)N * 8, stream));
+  long long sp_terminated = 0, sp_reward_sum = 0;
+  int64_t* h_actions = (int64_t*)malloc((size_t)N * 8);
+  for (int t = 0; t <= S; ++t) {
+    MNK_OK_(mnk_selfplay_step_random_logits(
+        planes_c, meta_c, N, m, n, k, /*logits=*/NULL, MNK_LOGITS_F32, mask_in, /*sample_seed=*/seed + 1, /*sample_seed_dev=*/NULL,
+        /*sample_step=*/(uint64_t)(t ? t - 1 : 0), /*sample_step_dev=*/NULL, /*sample_env_id0=*/0, /*deterministic=*/0, actions, logp,
+        pending, agent_side, /*forced_side=*/NULL, /*seed=*/seed, /*step=*/(uint64_t)t, /*step_dev=*/NULL, /*env_id0=*/0, sp_rewards,
+        terminated, /*obs=*/NULL, MNK_OBS_F32, mask_out, /*packed_obs=*/NULL, /*err=*/NULL, NULL, NULL, NULL, /*flags=*/0, stream));
+    if (t) {
+      HIP_OK(hipMemcpyAsync(h_dones, terminated, (size_t)N, hipMemcpyDeviceToHost, stream));
+      HIP_OK(hipMemcpyAsync(h_rewards, sp_rewards, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
+      HIP_OK(hipStreamSynchronize(stream));
+      for (int64_t i = 0; i < N; ++i) {
+        sp_terminated += h_dones[i] != 0;
+        sp_reward_sum += (long long)h_rewards[i];
+      }
+    }
+    uint8_t* swap = mask_in;  /* the next draw reads the mask this step wrote */
+    mask_in = mask_out;
+    mask_out = swap;
+  }
+  HIP_OK(hipMemcpyAsync(h_actions, actions, (size_t)N * 8, hipMemcpyDeviceToHost, stream));
+  uint64_t* h_planes_c = (uint64_t*)malloc(plane_words * 8);
+  uint32_t* h_meta_c = (uint32_t*)malloc((size_t)N * 4);
+  HIP_OK(hipMemcpyAsync(h_planes_c, planes_c, plane_words * 8, hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipMemcpyAsync(h_meta_c, meta_c, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipStreamSynchronize(stream));
+  const unsigned long long sp_actions_sum = checksum64((const uint64_t*)h_actions, (size_t)N);
+  const unsigned long long sp_planes_sum = checksum64(h_planes_c, plane_words), sp_meta_sum = checksum32(h_meta_c, (size_t)N);
+  free(h_planes_c);
+  free(h_meta_c);
+  hipFree(planes_c); hipFree(meta_c); hipFree(pending); hipFree(terminated); hipFree(mask_in); hipFree(mask_out);
+  hipFree(agent_side); hipFree(actions); hipFree(sp_rewards); hipFree(logp);
+  free(h_actions);
+
   long long counters[MNK_STATS_COUNTERS] = {0};
   for (int r = 0; r < MNK_STATS_REPLICAS; ++r)
     for (int c = 0; c < MNK_STATS_COUNTERS; ++c) counters[c] += (long long)h_stats[r * MNK_STATS_STRIDE + c];
@@ -146,11 +207,13 @@ int main(int argc, char** argv) {
 
   printf("abi=%d m=%d n=%d k=%d envs=%lld plies=%d seed=%llu episodes=%lld black_wins=%lld white_wins=%lld draws=%lld "
          "length_sum=%lld dones_in_records=%lld planes_sum=%llu meta_sum=%llu rec_planes_sum=%llu rec_meta_sum=%llu "
-         "per_ply_finished=%lld per_ply_wins=%lld per_ply_legal_last=%lld per_ply_state_equals_rollout=%d\n",
+         "per_ply_finished=%lld per_ply_wins=%lld per_ply_legal_last=%lld per_ply_state_equals_rollout=%d "
+         "sp_steps=%d sp_terminated=%lld sp_reward_sum=%lld sp_actions_sum=%llu sp_planes_sum=%llu sp_meta_sum=%llu\n",
          mnk_abi_version(), m, n, k, (long long)N, T, (unsigned long long)seed, counters[0], counters[1], counters[2],
          counters[3], counters[4], dones_in_records, (unsigned long long)checksum64(h_planes, plane_words),
          (unsigned long long)checksum32(h_meta, (size_t)N), (unsigned long long)checksum64(h_rec, rec_words),
-         (unsigned long long)checksum32(h_rec_meta, rec_metas), finished_b, wins_b, legal_last, same_state);
+         (unsigned long long)checksum32(h_rec_meta, rec_metas), finished_b, wins_b, legal_last, same_state, S, sp_terminated,
+         sp_reward_sum, sp_actions_sum, sp_planes_sum, sp_meta_sum);
 
   const int ok = same_state && finished_b == counters[0] && dones_in_records == counters[0] &&
                  wins_b == counters[1] + counters[2] && counters[1] + counters[2] + counters[3] == counters[0];

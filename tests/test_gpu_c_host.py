@@ -53,6 +53,23 @@ def test_c_host_equals_the_python_binding(hip, m, n, k, nenv, plies, seed):  # n
     assert got["rec_planes_sum"] == _weighted(rec.planes.cpu().numpy().view(np.uint64))
     assert got["rec_meta_sum"] == _weighted(rec.meta.cpu().numpy().view(np.uint32))
     assert got["per_ply_legal_last"] == int(env.observe()["action_mask"].sum().item())
+    # part (C), ABI v5: self-play agent-steps with the draw folded into the step kernel == the wrapper's step_logits
+    from selfplay.policy import HipSampler, RandomPolicy
+    from selfplay.torch_self_play_wrapper import TorchSelfPlayWrapper
+
+    wrap = TorchSelfPlayWrapper(hip.Env(m, n, k, nenv, device=DEV), seed=seed)
+    wrap.set_opponent(RandomPolicy(m * n, seed=0))  # (folds into the step kernel: draws on the wrapper's OPP stream)
+    obs, _ = wrap.reset()
+    sampler = HipSampler(seed=seed + 1)
+    term_count, reward_sum = 0, 0
+    for _ in range(got["sp_steps"]):
+        obs, rew, term, _, info = wrap.step_logits(None, obs["action_mask"], sampler)
+        term_count += int(term.sum().item())
+        reward_sum += int(rew.sum().item())
+    assert got["sp_terminated"] == term_count and got["sp_reward_sum"] == reward_sum
+    assert got["sp_actions_sum"] == _weighted(info["actions"].cpu().numpy().view(np.uint64))
+    assert got["sp_planes_sum"] == _weighted(wrap.env._planes.cpu().numpy().view(np.uint64))
+    assert got["sp_meta_sum"] == _weighted(wrap.env._meta.cpu().numpy().view(np.uint32))
 
 
 def test_c_host_equals_the_oracle():
