@@ -29,8 +29,10 @@ capture-safe (the built-in policies are: ``RandomPolicy`` folds into the step ke
 and its draw folds into the post kernel; its Philox key and position live in device words).  The reference installs a
 fresh ``deepcopy`` of the agent as opponent before EVERY rollout (train.py:106-114): ``set_opponent_weights`` does that
 to the captured opponent in place -- weights and buffers copied into the captured module's tensors, the sampler re-keyed
-through its device words -- with no new capture.  ``recapture()`` is only for an opponent of another architecture or
-policy class (or weights swapped by assignment).
+through its device words -- with no new capture.  ``wrapper.set_opponent(policy)`` on a captured wrapper does the
+same by itself when ``policy`` carries a network of the captured architecture (train.py:114 then runs unchanged), and
+marks the graph for a recapture at its next run otherwise.  ``recapture()`` by hand is only for weights swapped by
+assignment.
 """
 
 
@@ -82,6 +84,24 @@ class _CapturedOpponent:
         self.step_dev.zero_()    # a fresh policy starts at call 0
         return key
 
+    def adopt(self, policy) -> bool:
+        """``wrapper.set_opponent(policy)`` on a captured wrapper (the reference's train.py:106-114 does that before every
+        ``learn``): when ``policy`` carries a network of the captured opponent's architecture -- an ``NNPolicy`` or a
+        ``FusedNNPolicy`` around a ``deepcopy`` of the agent, a pool entry -- its weights go into the captured opponent in
+        place and the sampler is re-keyed (the policy's own key when it has one), the captured policy object stays
+        installed and True is returned; anything else (another kind of policy, another architecture) returns False: the
+        owner installs it and captures again at its next run."""
+        mine = getattr(self.wrapper.opponent_policy, "model", None)
+        theirs = getattr(policy, "model", None)
+        if self.sampler is None or mine is None or theirs is None:
+            return False
+        a, b = mine.state_dict(), theirs.state_dict()
+        if a.keys() != b.keys() or any(a[k].shape != b[k].shape or a[k].dtype != b[k].dtype for k in a):
+            return False
+        theirs_sampler = getattr(policy, "_sampler", None)
+        self.set_weights(theirs, seed=theirs_sampler.seed if theirs_sampler is not None else None)
+        return True
+
     def state(self):
         if self.sampler is None:
             return None
@@ -116,7 +136,9 @@ class GraphedAgentStep:
         self._opp = _CapturedOpponent(wrapper, self.dev)
         self.graphs = [None, None]
         self.outs = [None, None]
+        self._stale = False
         self.recapture()
+        wrapper._captured_by = self
 
     def _body(self, src: int):
         """One agent-step acting on slot ``src`` and leaving the next observation in slot ``1 - src`` (runs eagerly
@@ -159,6 +181,7 @@ class GraphedAgentStep:
             self.graphs[src] = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graphs[src]):
                 self.outs[src] = self._body(src)
+        self._stale = False
         # the two captures did not execute: the current observation is still in slot `cur`
 
     def set_opponent_weights(self, source, seed=None):
@@ -168,7 +191,16 @@ class GraphedAgentStep:
         ``recapture()`` would leave behind, minus the warm-up steps and the capture.  Returns the key."""
         return self._opp.set_weights(source, seed)
 
+    def adopt_opponent(self, policy) -> bool:
+        """called by ``wrapper.set_opponent``: see ``_CapturedOpponent.adopt``"""
+        if self._opp.adopt(policy):
+            return True
+        self._stale = True  # another kind of opponent: capture again before the next step
+        return False
+
     def step(self):
+        if self._stale:
+            self.recapture()
         src = self.cur
         self.graphs[src].replay()
         self.cur ^= 1
@@ -234,7 +266,9 @@ class GraphedRollout:
         wrapper.reset(out=spill)  # the first observation arrives where every later rollout finds its carried-over one
         self._opp = _CapturedOpponent(wrapper, self.dev)
         self.graph = None
+        self._stale = False
         self.recapture()
+        wrapper._captured_by = self
 
     def _obs_of(self, t):
         if self.dense:
@@ -300,6 +334,14 @@ class GraphedRollout:
         if self._opp.sampler is not None:
             self._opp.sampler.calls = 0
         self.buffer.ptr = self.buffer.n_steps  # the warm-up rollout filled the buffer
+        self._stale = False
+
+    def adopt_opponent(self, policy) -> bool:
+        """called by ``wrapper.set_opponent``: see ``_CapturedOpponent.adopt``"""
+        if self._opp.adopt(policy):
+            return True
+        self._stale = True  # another kind of opponent: the next run() is a recapture (which plays that rollout itself)
+        return False
 
     def set_opponent_weights(self, source, seed=None):
         """A new opponent before the next rollout WITHOUT a new capture (the reference does
@@ -342,6 +384,9 @@ class GraphedRollout:
                 m.copy_(sm)
 
     def run(self):
+        if self._stale:
+            self.recapture()  # (its warm-up IS this rollout)
+            return
         self.graph.replay()
         self.buffer.ptr = self.buffer.n_steps
 

@@ -65,11 +65,16 @@ class TorchSelfPlayWrapper:
         self._ep_return = self._ep_length = self._ep_stats = None  # see track_episodes()
         self.step_dev = None  # optional device int64[1] added to step_count inside the kernels (graph replays)
         self._sink = None     # see attach_sink()
+        self._captured_by = None  # the GraphedRollout / GraphedAgentStep that has captured this wrapper's step, if any
         self.fuse_opponent_draw = True  # a FusedNNPolicy opponent's draw runs inside mnk_selfplay_post_logits (False: as a
         self.last_opponent_actions = None  # launch of its own before mnk_selfplay_post -- same results, for A/B timing)
         self._truncated = torch.zeros(self.num_envs, dtype=torch.bool, device=self._dev)  # wrapper:66: always all-False
 
     def set_opponent(self, policy):  # reference wrapper:16-17
+        # a captured graph (selfplay.graphed) holds the opponent it was captured with: it takes the new policy's weights
+        # in place where it can (train.py:114 then works unchanged, no capture) and recaptures at its next run otherwise
+        if self._captured_by is not None and self._captured_by.adopt_opponent(policy):
+            return
         self.opponent_policy = policy
 
     def force_sides(self, sides) -> None:
@@ -293,6 +298,7 @@ class TorchSelfPlayWrapper:
             if opp is None:
                 raise RuntimeError("TorchSelfPlayWrapper: set_opponent(policy) before reset()/step()")
             opp_obs = torch.empty((n, 2, env.m, env.n), dtype=env.obs_dtype, device=dev)
+            fold_opp = getattr(opp, "fused_logits", False) and self.fuse_opponent_draw
             opp_mask = torch.empty((n, env.max_moves), dtype=torch.bool, device=dev)
             tail = (mnk_hip.ptr(self.pending_resets), mnk_hip.ptr(self.agent_side), mnk_hip.ptr(forced), self.seed, step,
                     mnk_hip.ptr(self.step_dev), self.env_id0, mnk_hip.ptr(rewards), mnk_hip.ptr(terminated),
@@ -307,7 +313,7 @@ class TorchSelfPlayWrapper:
                     mnk_hip.ptr(packed), mnk_hip.ptr(env._err), mnk_hip.ptr(self._ep_return), mnk_hip.ptr(self._ep_length),
                     mnk_hip.ptr(self._ep_stats), env._flags(), env._stream())
             opp_view = {"observation": opp_obs, "action_mask": opp_mask}
-            if getattr(opp, "fused_logits", False) and self.fuse_opponent_draw:
+            if fold_opp:
                 # FusedNNPolicy opponent: only its forward is the caller's; mask + softmax + draw happen inside the post
                 # kernel (wrapper:91-96 + policy.py:46-52 + cnn.py:69-79), on the opponent's own sampler stream
                 from selfplay.policy import HipSampler

@@ -296,8 +296,9 @@ def _eager_rollout(hip, w, buf, net, agent_sampler, obs):
 FIELDS = ("observations", "action_masks", "actions", "rewards", "dones", "values", "log_probs")
 
 
+@pytest.mark.parametrize("how", ["set_opponent_weights", "wrapper.set_opponent"])
 @pytest.mark.parametrize("nenv", [96, 700])
-def test_opponent_swap_without_recapture_equals_the_eager_loop(hip, nenv):
+def test_opponent_swap_without_recapture_equals_the_eager_loop(hip, nenv, how):
     """The reference installs a fresh deepcopy of the agent as opponent before EVERY rollout (train.py:106-114).
     ``GraphedRollout.set_opponent_weights`` does that to the captured opponent in place (weights, BatchNorm statistics,
     a new Philox key through the device word) with no new capture; the rollouts equal the eager loop with
@@ -315,7 +316,12 @@ def test_opponent_swap_without_recapture_equals_the_eager_loop(hip, nenv):
     graph = roll.graph
     got = [{f: getattr(bg, f)[:steps].clone() for f in FIELDS}]
     for j in range(1, rollouts):
-        roll.set_opponent_weights(sources[j], seed=100 + j)
+        if how == "set_opponent_weights":
+            roll.set_opponent_weights(sources[j], seed=100 + j)
+        else:  # the reference's own line (train.py:114): the captured wrapper adopts the policy's weights and key in place
+            kept = wg.opponent_policy
+            wg.set_opponent(hip.policy.FusedNNPolicy(copy.deepcopy(sources[j]), seed=100 + j))
+            assert wg.opponent_policy is kept
         roll.run()
         got.append({f: getattr(bg, f)[:steps].clone() for f in FIELDS})
     assert roll.graph is graph, "a new capture happened"
@@ -461,3 +467,51 @@ def test_graphed_agent_step_swaps_its_opponent_in_place(hip):
             assert torch.equal(o["obs"], prev["observation"]) and torch.equal(o["mask"], prev["action_mask"]), t
             assert torch.equal(o["actions"], actions) and torch.equal(o["log_probs"], logp), t
             assert torch.equal(o["rewards"], rew) and torch.equal(o["terminated"], term), t
+
+
+def test_set_opponent_of_another_kind_recaptures_at_the_next_run(hip):
+    """``wrapper.set_opponent`` on a captured wrapper with a policy the graph cannot adopt (no network / another
+    architecture): installed as it is, the graph captures again at its next ``run()`` -- whose warm-up IS that rollout --
+    and the stream of rollouts still equals the eager loop's.  An ``NNPolicy`` of the captured architecture is adopted
+    (weights in place, a fresh key)."""
+    m, n, k, nenv, steps = 9, 9, 5, 150, 4
+    c = m * n
+    net = TinyNet(m, n, 10).to(DEV).eval()
+    oppnet = TinyNet(m, n, 11).to(DEV).eval()
+    wg = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV), seed=7)
+    wg.set_opponent(hip.policy.FusedNNPolicy(copy.deepcopy(oppnet), seed=8))
+    bg = hip.Buffer(steps, nenv, (2, m, n), c, device=DEV)
+    roll = hip.graphed.GraphedRollout(wg, bg, net, seed=9)
+    first = roll.graph
+    got = [{f: getattr(bg, f)[:steps].clone() for f in FIELDS}]
+    wg.set_opponent(LowestLegalPolicy())            # cannot be adopted
+    assert isinstance(wg.opponent_policy, LowestLegalPolicy) and roll._stale
+    roll.run()                                      # recaptures; plays rollout 1 while doing so
+    assert roll.graph is not first and not roll._stale
+    got.append({f: getattr(bg, f)[:steps].clone() for f in FIELDS})
+    roll.run()
+    got.append({f: getattr(bg, f)[:steps].clone() for f in FIELDS})
+
+    we = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV), seed=7)
+    be = hip.Buffer(steps, nenv, (2, m, n), c, device=DEV)
+    we.attach_sink(be)
+    we.set_opponent(hip.policy.FusedNNPolicy(copy.deepcopy(oppnet), seed=8))
+    agent = hip.policy.HipSampler(seed=9)
+    obs, _ = we.reset()
+    for j in range(3):
+        if j == 1:
+            we.set_opponent(LowestLegalPolicy())
+        obs = _eager_rollout(hip, we, be, net, agent, obs)
+        for f in FIELDS:
+            assert torch.equal(getattr(be, f)[:steps], got[j][f]), (j, f)
+    # an NNPolicy around a network of the captured architecture: adopted in place (no new capture), weights equal
+    w2 = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV), seed=1)
+    w2.set_opponent(hip.policy.FusedNNPolicy(copy.deepcopy(oppnet), seed=2))
+    r2 = hip.graphed.GraphedRollout(w2, hip.Buffer(steps, nenv, (2, m, n), c, device=DEV), net, seed=3)
+    graph, kept = r2.graph, w2.opponent_policy
+    w2.set_opponent(hip.policy.NNPolicy(copy.deepcopy(net)))
+    assert w2.opponent_policy is kept and not r2._stale
+    for a, b in zip(kept.model.state_dict().values(), net.state_dict().values()):
+        assert torch.equal(a, b)
+    r2.run()
+    assert r2.graph is graph
