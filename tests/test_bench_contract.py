@@ -134,3 +134,19 @@ def test_round4_profile_summary_splits_the_phases():
     assert m and int(m.group(1)) == 64
     line = json.loads(re.search(r"```json\n(.*?)\n```", text, flags=re.S).group(1))
     assert float(m.group(2)) <= line["ms_per_step"] * 1e3
+
+
+def test_round4_rehearsal_lines_carry_the_exchange_group_size():
+    """Round 4: `--exchange-every J` in the rehearsed multi-GPU code path (one RCCL rank) and with two gloo ranks: the line
+    says how many chunks one all-gather carries and how many bytes that is; bytes per env-step do not change."""
+    with open(os.path.join(ROOT, "profiles", "r04_bench_rehearse_exchange_lines.json")) as f:
+        lines = [json.loads(ln) for ln in f.read().splitlines() if ln.startswith("{")]
+    assert [d["exchange"]["chunks_per_exchange"] for d in lines] == [1, 2, 1, 2]
+    for d in lines:
+        x = d["exchange"]
+        assert x["bytes_per_rank_per_exchange"] == pytest.approx(x["bytes_per_rank_per_chunk"] * x["chunks_per_exchange"])
+        assert "C ABI, RCCL" in x["transport"] and x["alone"]["ncclAllGather_ms"] > 0 and "exchange_hung" not in d
+        assert d["roofline"]["frac_wall"] <= 1.02 * d["roofline"]["frac_kernel_events"]
+    assert {round(d["exchange"]["bytes_per_env_step"], 3) for d in lines} == {0.893, 1.016, 28.0}
+    d = _line("r04_bench_gloo2_exchange_every_line.json")
+    assert d["n_gpus"] == 2 and d["exchange"]["chunks_per_exchange"] == 2 and d["exchange"]["bytes_per_env_step"] == pytest.approx(0.893, abs=1e-3)
