@@ -681,6 +681,11 @@ print("EMIT_OK")
     env = dict(os.environ, MNK_EMIT_THREADS="512", MNK_EMIT_ENVS="48")
     out = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=300)
     assert "EMIT_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    # round-3 advisor finding: MNK_EMIT_ENVS=128 is legal and so is MNK_EMIT_THREADS=64, but together the envs 64..127 of
+    # every workgroup had no lane to play them.  mnk_block_threads() now never hands out fewer threads than envs.
+    for knobs in ({"MNK_EMIT_ENVS": "128", "MNK_EMIT_THREADS": "64"}, {"MNK_EMIT_ENVS": "128"}, {"MNK_EMIT_ENVS": "16", "MNK_EMIT_THREADS": "64"}):
+        out = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, **knobs), capture_output=True, text=True, timeout=300)
+        assert "EMIT_OK" in out.stdout, str(knobs) + out.stdout[-2000:] + out.stderr[-4000:]
 
 
 def test_empty_and_single_env_batches(hip):
