@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define MNK_ABI_VERSION 5
+#define MNK_ABI_VERSION 6
 
 /* status codes (host-side argument checks) */
 #define MNK_OK 0
@@ -315,6 +315,35 @@ int64_t mnk_jit_compile_rollout(int m, int n, int k, int record, int act_bytes);
 #define MNK_JIT_ROLLOUT_PAIR 2
 int64_t mnk_jit_compile_kernel(int m, int n, int k, int record, int act_bytes, int kind);
 const char* mnk_jit_last_error(void);
+/* ABI 6: the API-level kernels are specialised at run time too.  On a board without a built-in variant the kernels behind
+ * mnk_step / mnk_step_random / mnk_observe / mnk_sample_legal / mnk_unpack_records / mnk_gather_obs / mnk_selfplay_* start
+ * on generic code (run-time shift amounts, table write-out) and switch to the board's own variant -- compile-time
+ * geometry, the packed write-out, and for mnk_selfplay_*_logits the draw folded into the step kernel for any row width --
+ * once they are hot: 128 launches or 2^22 items of that kernel on that board in this process (about a second of hiprtc per
+ * kernel, then a code object load).  MNK_JIT_API=1 (or MNK_JIT=1): at the first launch; =0: never.  Results are identical
+ * either way.  Nothing is compiled while the launch's stream is being captured into a hipGraph: call mnk_jit_prepare
+ * before the capture.  `kind` / the bits of `kinds`: */
+#define MNK_JIT_API_STEP 0            /* mnk_step, full batch */
+#define MNK_JIT_API_STEP_DRAW 1       /* mnk_step_random */
+#define MNK_JIT_API_STEP_SUBSET 2     /* mnk_step with active_idx */
+#define MNK_JIT_API_OBSERVE 3         /* mnk_observe, mnk_unpack_boards */
+#define MNK_JIT_API_SAMPLE_LEGAL 4    /* mnk_sample_legal */
+#define MNK_JIT_API_UNPACK_RECORDS 5  /* mnk_unpack_records */
+#define MNK_JIT_API_GATHER_OBS 6      /* mnk_gather_obs */
+#define MNK_JIT_API_SP_PRE 7          /* mnk_selfplay_pre */
+#define MNK_JIT_API_SP_POST 8         /* mnk_selfplay_post */
+#define MNK_JIT_API_SP_STEP 9         /* mnk_selfplay_step_random */
+#define MNK_JIT_API_SP_DRAW 10        /* + 3 * logits form (0 f32, 1 bf16, 2 none) + (0 pre, 1 post, 2 step_random):
+                                         mnk_selfplay_pre_logits / _post_logits / _step_random_logits */
+#define MNK_JIT_API_COUNT 19
+/* compiles only (no GPU needed): code object bytes, or a negative status with the log in mnk_jit_last_error() */
+int64_t mnk_jit_compile_api(int m, int n, int k, int kind);
+/* compiles and loads, on the current device, the variants named by the bits of `kinds` NOW (kinds == 0: of every kernel
+ * launched on this board so far -- after a warm-up run, exactly what a capture is going to launch): the number ready, 0
+ * for a board with a built-in variant or with MNK_JIT_API / MNK_JIT = 0, or a negative status */
+int mnk_jit_prepare(int m, int n, int k, int64_t kinds);
+/* 1 when the board's own variant of `kind` is loaded on the current device (what the next launch will run), else 0 */
+int mnk_jit_api_ready(int m, int n, int k, int kind);
 
 /* The multi-GPU exchange format.  A shard's rollout is a pure function of its chunk-start state and
  * its actions, so the action log, optionally written by mnk_rollout_random, is what ranks all-gather

@@ -50,6 +50,24 @@ struct MnkGeom {
 
 __device__ __forceinline__ uint32_t mnk_div(uint32_t x, uint32_t magic) { return __umulhi(x, magic); }
 
+__host__ __device__ inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// A masked draw from a policy head's logits (mnk_sample_logits; the mnk_selfplay_*_logits entry points fold it into a
+// step kernel): where the logits and the mask live, the sampler's Philox key and position, where the results go.
+struct MnkSample {
+  const void* logits;        // [N][C] f32 / bf16 bit patterns; NULL = all-zero logits (uniform over the mask)
+  int logits_dtype;          // MNK_LOGITS_F32 / MNK_LOGITS_BF16
+  const uint8_t* mask;       // [N][C]
+  uint64_t seed;
+  const uint64_t* seed_dev;  // optional device word that REPLACES seed (a captured graph's sampler can be re-keyed)
+  uint64_t step;
+  const uint64_t* step_dev;  // optional device word ADDED to step
+  int64_t env_id0;           // Philox row id of row 0
+  int deterministic;
+  int64_t* actions;          // out [N]
+  float* logp;               // out [N], optional
+};
+
 template <int CN>
 __device__ __forceinline__ int geom_n(const MnkGeom& g) { return CN ? CN : g.n; }
 template <int CK>

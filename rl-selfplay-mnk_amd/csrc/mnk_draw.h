@@ -259,11 +259,19 @@ __device__ __forceinline__ Drawn draw_row(const float* lrow, int C, float u, int
 // 8 lanes per row 9.9 us; profiles/r02_api_kernels.md).  The cell order of the inverse-CDF walk is lane-major, so two
 // kernels give the same action for the same uniform only when they use the same shape: this table is the one place
 // that names it.
-template <int C> struct Shape;
-template <> struct Shape<81> { static constexpr int LPR = 4, K = 21; };    // 9x9
-template <> struct Shape<9> { static constexpr int LPR = 4, K = 3; };      // 3x3
-template <> struct Shape<169> { static constexpr int LPR = 8, K = 22; };   // 13x13
-template <> struct Shape<225> { static constexpr int LPR = 16, K = 15; };  // 15x15
-template <> struct Shape<361> { static constexpr int LPR = 16, K = 23; };  // 19x19
+// Every other row width takes its shape by size.  EXACT (only a lane's last cell can lie outside the row) holds for the
+// measured shapes.  As constexpr functions of the row width, so that the host can size the LDS of a run-time compiled
+// kernel whose Draw<LT, C> it never instantiates.
+__host__ __device__ constexpr bool shape_measured(int C) { return C == 81 || C == 9 || C == 169 || C == 225 || C == 361; }
+__host__ __device__ constexpr int shape_lpr(int C) {
+  return (C == 81 || C == 9) ? 4 : (C == 169 ? 8 : ((C == 225 || C == 361) ? 16 : (C <= 32 ? 4 : (C <= 96 ? 8 : (C <= 256 ? 16 : 32)))));
+}
+__host__ __device__ constexpr int shape_k(int C) {
+  return C == 81 ? 21 : (C == 9 ? 3 : (C == 169 ? 22 : (C == 225 ? 15 : (C == 361 ? 23 : (C <= 32 ? 8 : (C <= 96 ? 12 : (C <= 512 ? 16 : 32)))))));
+}
+template <int C> struct Shape {
+  static constexpr int LPR = shape_lpr(C), K = shape_k(C);
+  static constexpr bool EXACT = shape_measured(C);
+};
 
 }  // namespace mnk_draw

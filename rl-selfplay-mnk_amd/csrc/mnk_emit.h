@@ -45,19 +45,32 @@ __host__ __device__ inline int mnk_seg_words(int NW, int n) {  // SW: words of o
   return (cw + 1) | 1;
 }
 
-// may this geometry take the packed write-out?  (the boards MNK_DISPATCH has compile-time variants for; 16 mask bytes
-// must not span more than two envs)
-__host__ __device__ inline bool mnk_geom_packed(int n, int k, int NW, int C) {
-  const bool fixed = (n == 9 && k == 5 && NW == 3) || (n == 13 && k == 5 && NW == 6) || (n == 15 && k == 5 && NW == 8) ||
-                     (n == 19 && k == 5 && NW == 12);
-  return fixed && C >= 16;
+// The boards the ahead-of-time dispatch (MNK_DISPATCH, mnk_host.h) has compile-time geometry for; every other board gets
+// its compile-time variant from hiprtc once it is hot (mnk_jit.hip).
+__host__ __device__ inline bool mnk_geom_builtin(int n, int k, int NW) {
+  return (n == 9 && k == 5 && NW == 3) || (n == 3 && k == 3 && NW == 1) || (n == 13 && k == 5 && NW == 6) ||
+         (n == 15 && k == 5 && NW == 8) || (n == 19 && k == 5 && NW == 12);
 }
 
-__host__ __device__ inline size_t mnk_stage_bytes(int NW, int C, int B, int n = 0, int k = 0) {
+// does a kernel variant with compile-time geometry (CN = n) write out in the packed form on a board of C cells?
+// (16 mask bytes must not span more than two envs; the squeeze moves a board row as one 32-bit word)
+__host__ __device__ inline bool mnk_packed_cells(int n, int C) { return C >= 16 && n <= 31; }
+
+// host side of the same rule for the ahead-of-time kernels: what MNK_DISPATCH will pick for this geometry
+__host__ __device__ inline bool mnk_geom_packed(int n, int k, int NW, int C) {
+  return mnk_geom_builtin(n, k, NW) && mnk_packed_cells(n, C);
+}
+
+// dynamic LDS of the write-out stage; `packed`: the launched variant has compile-time geometry and C >= 16
+__host__ __device__ inline size_t mnk_stage_bytes(int NW, int C, int B, int n, bool packed) {
   size_t bytes = (size_t)3 * NW * mnk_stage_stride(B) * 4 + (size_t)3 * C * 4;
-  if (mnk_geom_packed(n, k, NW, C)) bytes += (size_t)(3 * B + 2) * mnk_seg_words(NW, n) * 4;
+  if (packed) bytes += (size_t)(3 * B + 2) * mnk_seg_words(NW, n) * 4;
   return bytes;
 }
+
+// in a kernel: is this variant (compile-time board width CN, 0 = generic) on the packed write-out?
+template <int CN>
+__device__ __forceinline__ bool mnk_packed_form(const MnkGeom& g) { return CN != 0 && mnk_packed_cells(CN, g.C); }
 
 __device__ __forceinline__ MnkStage mnk_stage_carve(void* lds, const MnkGeom& g, int B) {
   MnkStage s;
@@ -68,8 +81,9 @@ __device__ __forceinline__ MnkStage mnk_stage_carve(void* lds, const MnkGeom& g,
   return s;
 }
 
+template <int CN>
 __device__ __forceinline__ void mnk_stage_tables(const MnkStage& s, const MnkGeom& g, int B, int tid, int nthreads) {
-  if (mnk_geom_packed(g.n, g.k, g.NW, g.C)) return;  // the packed write-out needs no cell tables
+  if (mnk_packed_form<CN>(g)) return;  // the packed write-out needs no cell tables
   for (int r = tid; r < 3 * g.C; r += nthreads) {
     const int plane = r >= 2 * g.C ? 2 : (r >= g.C ? 1 : 0);
     const uint32_t cell = (uint32_t)(r - plane * g.C);
@@ -240,8 +254,8 @@ __device__ __forceinline__ void mnk_write_out(const MnkStage& s, const MnkGeom& 
                                               uint8_t* mask, int vec_ok, int tid, int nthreads) {
   __syncthreads();  // the stage is complete
   const bool ovec = vec_ok & 1, mvec = (vec_ok >> 1) & 1;
-  if constexpr (CN != 0 && NW >= 3) {
-    if (mnk_geom_packed(CN, CK, NW, g.C)) {
+  if constexpr (CN != 0 && CN <= 31) {
+    if (mnk_packed_form<CN>(g)) {
       // the pad segments that follow the last channel / legal segment: read (never used) by the last groups
       constexpr int SW = ((((32 * NW / (CN + 1)) * CN + 31) / 32) + 1) | 1;
       if (tid < SW) {

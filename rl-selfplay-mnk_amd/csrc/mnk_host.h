@@ -7,6 +7,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <tuple>
+#include <utility>
+
 #include "mnk_device.h"
 #include "mnk_emit.h"
 
@@ -60,8 +63,6 @@ inline int mnk_launch_status(const char* what) {
   return MNK_ELAUNCH;
 }
 
-__host__ __device__ inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
-
 // Developer knobs from the environment (A/B timing, parity tests of every kernel form), read ONCE -- a launch used to
 // cost four or five getenv() calls, which is nothing beside a 90 us rollout launch but not beside a 5 us step.
 // mnk_reload_config() (C ABI; mnk_hip.reload_config() in Python) reads them again after the environment has changed.
@@ -69,6 +70,8 @@ struct MnkConfig {
   int pair_override = -1;  // MNK_ROLLOUT_PAIR=0/1: never / always two lanes per env (unset: by batch size)
   int form = 0;            // MNK_ROLLOUT_FORM=lane|pair|pairw|ws2|ws4 -> 1..5 (unset / unknown: 0)
   int jit = -1;            // MNK_JIT=0/1 (unset: run-time specialisation from 2^20 env-steps per launch)
+  int jit_api = -1;        // MNK_JIT_API=0/1: the same for the API-level kernels alone (unset: what MNK_JIT says; both unset:
+                           // a board's own variant is compiled once the kernel is hot, mnk_jit_api_function)
   bool saddr_off = false;  // MNK_ROLLOUT_SADDR=0: no 32-bit-offset record stores
   int emit_envs = 0;       // MNK_EMIT_ENVS=16|32|64|128: envs per workgroup of the write-out kernels (0: by batch size)
   int emit_threads = 0;    // MNK_EMIT_THREADS=64|128|256 (the kernels are __launch_bounds__(256); 0: by output set)
@@ -85,6 +88,8 @@ inline MnkConfig mnk_read_config() {
       if (!strcmp(v, names[f])) c.form = f;
   }
   if (const char* v = getenv("MNK_JIT")) c.jit = atoi(v) != 0 ? 1 : 0;
+  c.jit_api = c.jit;
+  if (const char* v = getenv("MNK_JIT_API")) c.jit_api = atoi(v) != 0 ? 1 : 0;
   if (const char* v = getenv("MNK_ROLLOUT_SADDR")) c.saddr_off = atoi(v) == 0;
   if (const char* v = getenv("MNK_EMIT_ENVS")) {
     const int t = atoi(v);
@@ -184,21 +189,6 @@ inline bool mnk_act_format_ok(int act, int C) {
          (act == MNK_ACT_U8P1 && C > 256 && C <= 512);  // (9 bits per action; only the boards that need it have kernel variants)
 }
 
-// A masked draw from a policy head's logits (mnk_sample_logits; the mnk_selfplay_*_logits entry points fold it into a
-// step kernel): where the logits and the mask live, the sampler's Philox key and position, where the results go.
-struct MnkSample {
-  const void* logits;        // [N][C] f32 / bf16 bit patterns; NULL = all-zero logits (uniform over the mask)
-  int logits_dtype;          // MNK_LOGITS_F32 / MNK_LOGITS_BF16
-  const uint8_t* mask;       // [N][C]
-  uint64_t seed;
-  const uint64_t* seed_dev;  // optional device word that REPLACES seed (a captured graph's sampler can be re-keyed)
-  uint64_t step;
-  const uint64_t* step_dev;  // optional device word ADDED to step
-  int64_t env_id0;           // Philox row id of row 0
-  int deterministic;
-  int64_t* actions;          // out [N]
-  float* logp;               // out [N], optional
-};
 // the draw as a launch of its own (mnk_sample.hip)
 int mnk_launch_sample(const MnkSample& sa, int64_t N, int C, hipStream_t s);
 
@@ -257,3 +247,47 @@ bool mnk_rollout_pairw_supported(const MnkGeom& g);
 void mnk_launch_rollout_pairw(const MnkGeom& g, uint64_t* planes, uint32_t* meta, int64_t N, int T, uint64_t seed,
                               uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
                               void* act_log, int act_bytes, void* stream);
+
+// ------------------------------------------------------------------ run-time specialised API-level kernels (mnk_jit.hip)
+// The kernels of mnk_api_kernels.h / mnk_selfplay_kernels.h, compiled by hiprtc with the board's NW / n / k (and, for the
+// forms with a folded-in draw, its cell count) as template arguments.  Boards with a built-in variant never get here.
+enum MnkJitApiKind {  // (the public names: MNK_JIT_API_* of include/mnk_hip.h)
+  MNK_JK_STEP = MNK_JIT_API_STEP,                      // k_step_full<NW, CN, CK, false>
+  MNK_JK_STEP_DRAW = MNK_JIT_API_STEP_DRAW,            // k_step_full<NW, CN, CK, true>
+  MNK_JK_STEP_SUBSET = MNK_JIT_API_STEP_SUBSET,        // k_step_subset
+  MNK_JK_OBSERVE = MNK_JIT_API_OBSERVE,                // k_observe          (never looks at k: compiled with CK = 0)
+  MNK_JK_SAMPLE_LEGAL = MNK_JIT_API_SAMPLE_LEGAL,      // k_sample_legal     (CK = 0)
+  MNK_JK_UNPACK_RECORDS = MNK_JIT_API_UNPACK_RECORDS,  // k_unpack_records   (CK = 0)
+  MNK_JK_GATHER_OBS = MNK_JIT_API_GATHER_OBS,          // k_gather_obs       (CK = 0)
+  MNK_JK_SP_PRE = MNK_JIT_API_SP_PRE,                  // k_selfplay_pre / _post / _step_random <NW, CN, CK, NoDraw>
+  MNK_JK_SP_POST = MNK_JIT_API_SP_POST,
+  MNK_JK_SP_STEP = MNK_JIT_API_SP_STEP,
+  MNK_JK_SP_DRAW = MNK_JIT_API_SP_DRAW,  // + 3 * lt + which: <NW, CN, CK, Draw<LT, C>>, lt 0 f32 / 1 bf16 / 2 no logits
+  MNK_JK_COUNT = MNK_JIT_API_COUNT
+};
+inline bool mnk_jit_kind_any_k(int kind) { return kind >= MNK_JK_OBSERVE && kind <= MNK_JK_GATHER_OBS; }
+
+// The board's own variant of API kernel `kind`, or nullptr = launch the ahead-of-time kernel: the board has a built-in
+// variant, MNK_JIT_API / MNK_JIT = 0, the kernel is not hot yet (fewer than 128 launches and 2^22 items on this board in
+// this process; MNK_JIT_API / MNK_JIT = 1: compile at the first launch), `stream` is being captured and the variant does
+// not exist yet (nothing is compiled or loaded under a capture), or the compilation failed (mnk_jit_last_error).
+hipFunction_t mnk_jit_api_function(const MnkGeom& g, int kind, int64_t items, hipStream_t stream);
+
+template <typename... P, size_t... I>
+inline hipError_t mnk_module_launch_impl(hipFunction_t fn, dim3 grid, dim3 block, size_t lds, hipStream_t s,
+                                         std::tuple<P...>& params, std::index_sequence<I...>) {
+  void* ptrs[] = {(void*)&std::get<I>(params)...};
+  return hipModuleLaunchKernel(fn, grid.x, grid.y, grid.z, block.x, block.y, block.z, (unsigned)lds, s, ptrs, nullptr);
+}
+
+// Launches a run-time compiled kernel.  `signature`: any ahead-of-time instantiation of the same kernel template -- its
+// parameter list is the module function's, so every argument is converted to the exact parameter type here and a
+// mismatch in the number of arguments does not compile.
+template <typename... P, typename... A>
+inline void mnk_module_launch(void (*signature)(P...), hipFunction_t fn, dim3 grid, dim3 block, size_t lds, hipStream_t s,
+                              A&&... a) {
+  (void)signature;
+  static_assert(sizeof...(P) == sizeof...(A), "argument list differs from the kernel's parameter list");
+  std::tuple<P...> params{static_cast<P>(a)...};
+  (void)mnk_module_launch_impl(fn, grid, block, lds, s, params, std::index_sequence_for<P...>{});  // (mnk_launch_status reads the error)
+}

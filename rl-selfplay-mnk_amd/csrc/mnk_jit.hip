@@ -130,7 +130,181 @@ int mnk_jit_launch_rollout_lanes(hipFunction_t fn, MnkGeom g, uint64_t* planes, 
   return MNK_OK;
 }
 
+// ------------------------------------------------------------------ API-level kernels (round 4)
+// The kernels behind mnk_step / mnk_observe / mnk_sample_legal / mnk_unpack_records / mnk_gather_obs / mnk_selfplay_* of
+// a board without a built-in variant ran generic code: wave-uniform loops over run-time shift amounts and the table form
+// of the write-out, 1.3-1.4x slower than a compiled board of the same size.  Here hiprtc instantiates the same templates
+// (mnk_api_kernels.h, mnk_selfplay_kernels.h: the text hipcc compiles, embedded at build time) with the board's NW / n / k
+// -- one kernel per program, named by a hiprtc name expression -- which also puts the board on the packed write-out
+// (mnk_emit.h) and lets the self-play step kernels fold the masked draw in for ANY row width (mnk_draw::Shape).
+namespace {
+
+struct ApiEntry {
+  Compiled c;
+  uint64_t launches = 0, items = 0;
+};
+// (device, m, n, k or 0, kind)
+std::map<std::tuple<int, int, int, int, int>, ApiEntry> g_api_cache;
+
+// the template-id of API kernel `kind` on this board, e.g. "k_step_full<5, 12, 5, false>"
+std::string api_kernel_name(const MnkGeom& g, int kind) {
+  const int ck = mnk_jit_kind_any_k(kind) ? 0 : g.k;
+  const std::string geo = std::to_string(g.NW) + ", " + std::to_string(g.n) + ", " + std::to_string(ck);
+  switch (kind) {
+    case MNK_JK_STEP: return "k_step_full<" + geo + ", false>";
+    case MNK_JK_STEP_DRAW: return "k_step_full<" + geo + ", true>";
+    case MNK_JK_STEP_SUBSET: return "k_step_subset<" + geo + ">";
+    case MNK_JK_OBSERVE: return "k_observe<" + geo + ">";
+    case MNK_JK_SAMPLE_LEGAL: return "k_sample_legal<" + geo + ">";
+    case MNK_JK_UNPACK_RECORDS: return "k_unpack_records<" + geo + ">";
+    case MNK_JK_GATHER_OBS: return "k_gather_obs<" + geo + ">";
+    default: break;
+  }
+  static const char* which[] = {"k_selfplay_pre", "k_selfplay_post", "k_selfplay_step_random"};
+  if (kind >= MNK_JK_SP_PRE && kind <= MNK_JK_SP_STEP) return std::string(which[kind - MNK_JK_SP_PRE]) + "<" + geo + ", NoDraw>";
+  static const char* lts[] = {"float", "uint16_t", "void"};
+  const int d = kind - MNK_JK_SP_DRAW;
+  return std::string(which[d % 3]) + "<" + geo + ", Draw<" + lts[d / 3] + ", " + std::to_string(g.C) + "> >";
+}
+
+// compiles API kernel `kind` for this geometry (no GPU needed): code object in `code`, mangled name in `lowered`
+bool compile_api(const MnkGeom& g, int kind, std::vector<char>& code, std::string& lowered) {
+  static const char* program = "#include \"mnk_selfplay_kernels.h\"\n";  // (includes mnk_api_kernels.h)
+  hiprtcProgram prog = nullptr;
+  if (hiprtcCreateProgram(&prog, program, "mnk_jit_api.hip", MNK_JIT_HEADER_COUNT, mnk_jit_header_texts,
+                          mnk_jit_header_names) != HIPRTC_SUCCESS) {
+    snprintf(g_jit_err, sizeof(g_jit_err), "hiprtcCreateProgram failed");
+    return false;
+  }
+  const std::string expr = "&" + api_kernel_name(g, kind);
+  bool ok = hiprtcAddNameExpression(prog, expr.c_str()) == HIPRTC_SUCCESS;
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+  hiprtcResult rc = HIPRTC_SUCCESS;
+  if (ok) rc = hiprtcCompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+  if (!ok || rc != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n, '\0');
+    if (n) hiprtcGetProgramLog(prog, &log[0]);
+    snprintf(g_jit_err, sizeof(g_jit_err), "hiprtc (%s): %s\n%.1700s", expr.c_str(), ok ? hiprtcGetErrorString(rc) : "name expression rejected",
+             log.c_str());
+    hiprtcDestroyProgram(&prog);
+    return false;
+  }
+  const char* name = nullptr;
+  if (hiprtcGetLoweredName(prog, expr.c_str(), &name) != HIPRTC_SUCCESS || !name) {
+    snprintf(g_jit_err, sizeof(g_jit_err), "hiprtcGetLoweredName(%s) failed", expr.c_str());
+    hiprtcDestroyProgram(&prog);
+    return false;
+  }
+  lowered = name;
+  size_t n = 0;
+  hiprtcGetCodeSize(prog, &n);
+  code.resize(n);
+  hiprtcGetCode(prog, code.data());
+  hiprtcDestroyProgram(&prog);
+  return n > 0;
+}
+
+bool api_kind_ok(const MnkGeom& g, int kind) {
+  if (kind < 0 || kind >= MNK_JK_COUNT) return false;
+  return kind < MNK_JK_SP_DRAW || g.C <= 1024;
+}
+
+// compile + load on the current device (g_mu held)
+hipFunction_t api_build(ApiEntry& e, const MnkGeom& g, int kind) {
+  std::vector<char> code;
+  std::string lowered;
+  if (!compile_api(g, kind, code, lowered)) { e.c.failed = true; return nullptr; }
+  if (hipModuleLoadData(&e.c.module, code.data()) != hipSuccess ||
+      hipModuleGetFunction(&e.c.fn, e.c.module, lowered.c_str()) != hipSuccess) {
+    snprintf(g_jit_err, sizeof(g_jit_err), "hipModuleLoadData / hipModuleGetFunction(%s) failed: %s", lowered.c_str(),
+             hipGetErrorString(hipGetLastError()));
+    e.c.failed = true;
+    e.c.fn = nullptr;
+    return nullptr;
+  }
+  e.c.code_bytes = code.size();
+  return e.c.fn;
+}
+
+}  // namespace
+
+hipFunction_t mnk_jit_api_function(const MnkGeom& g, int kind, int64_t items, hipStream_t stream) {
+  const int jit = mnk_config().jit_api;
+  if (jit == 0 || mnk_geom_builtin(g.n, g.k, g.NW) || !api_kind_ok(g, kind)) return nullptr;
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(g_mu);
+  ApiEntry& e = g_api_cache[std::make_tuple(device, g.m, g.n, mnk_jit_kind_any_k(kind) ? 0 : g.k, kind)];
+  if (e.c.fn || e.c.failed) return e.c.fn;
+  e.launches += 1;
+  e.items += (uint64_t)(items > 0 ? items : 0);
+  if (jit != 1 && e.launches < 128 && e.items < (1ull << 22)) return nullptr;  // not hot yet
+  if (stream) {  // nothing is compiled or loaded while the stream is being captured into a graph
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+  }
+  return api_build(e, g, kind);
+}
+
 extern "C" {
+
+// Compiles (does not load) API kernel `kind` (MnkJitApiKind, mnk_host.h) of a geometry: code object size in bytes or a
+// negative MNK_E* code.  Needs no GPU: the build check and the CPU test suite use it.
+int64_t mnk_jit_compile_api(int m, int n, int k, int kind) {
+  MnkGeom g;
+  const int rc = mnk_check_geom(m, n, k, &g);
+  if (rc != MNK_OK) return rc;
+  if (!api_kind_ok(g, kind)) return MNK_EINVAL;
+  std::vector<char> code;
+  std::string lowered;
+  if (!compile_api(g, kind, code, lowered)) return MNK_ELAUNCH;
+  return (int64_t)code.size();
+}
+
+// Compiles and loads, on the current device, the board's own variants of the API kernels named by the bits of
+// `kinds` (bit MnkJitApiKind) now instead of when they get hot -- before a stream capture, where nothing can be compiled.
+// kinds == 0: every kernel that has been launched on this board so far (on this device, in this process): a warm-up run
+// followed by mnk_jit_prepare(m, n, k, 0) prepares exactly what the capture is going to launch.  Returns the number of
+// variants ready, 0 for a board with a built-in variant or with MNK_JIT_API / MNK_JIT = 0, or a negative MNK_E* code
+// (mnk_jit_last_error says which kernel failed).
+int mnk_jit_prepare(int m, int n, int k, int64_t kinds) {
+  MnkGeom g;
+  const int rc = mnk_check_geom(m, n, k, &g);
+  if (rc != MNK_OK) return rc;
+  if (mnk_config().jit_api == 0 || mnk_geom_builtin(g.n, g.k, g.NW)) return 0;
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return MNK_ELAUNCH;
+  std::lock_guard<std::mutex> lock(g_mu);
+  int ready = 0;
+  for (int kind = 0; kind < MNK_JK_COUNT; ++kind) {
+    if (!api_kind_ok(g, kind)) continue;
+    const auto key = std::make_tuple(device, g.m, g.n, mnk_jit_kind_any_k(kind) ? 0 : g.k, kind);
+    if (kinds == 0) {
+      auto it = g_api_cache.find(key);
+      if (it == g_api_cache.end() || (it->second.launches == 0 && !it->second.c.fn)) continue;
+    } else if (!((kinds >> kind) & 1)) {
+      continue;
+    }
+    ApiEntry& e = g_api_cache[key];
+    if (!e.c.fn && !e.c.failed) api_build(e, g, kind);
+    if (!e.c.fn) return MNK_ELAUNCH;
+    ++ready;
+  }
+  return ready;
+}
+
+// is the board's own variant of API kernel `kind` loaded on the current device?  (1 / 0; what a launch would use)
+int mnk_jit_api_ready(int m, int n, int k, int kind) {
+  MnkGeom g;
+  if (mnk_check_geom(m, n, k, &g) != MNK_OK || !api_kind_ok(g, kind)) return 0;
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return 0;
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_api_cache.find(std::make_tuple(device, g.m, g.n, mnk_jit_kind_any_k(kind) ? 0 : g.k, kind));
+  return it != g_api_cache.end() && it->second.c.fn ? 1 : 0;
+}
 
 const char* mnk_jit_last_error(void) { return g_jit_err; }
 

@@ -8,7 +8,8 @@
 // B consecutive envs, and the same env -> workgroup map in every kernel so an env's
 // state stays in the L2 of the XCD that touched it last.
 #include "mnk_host.h"
-#include "mnk_selfplay_kernels.h"
+#include "mnk_api_kernels.h"
+#include "mnk_selfplay_host.h"
 
 // ------------------------------------------------------------------ reset
 __global__ void k_reset_idx(uint64_t* planes, uint32_t* meta, int64_t N, int W, const int64_t* idx, int64_t R,
@@ -27,103 +28,6 @@ __global__ void k_reset_mask(uint64_t* planes, uint32_t* meta, int64_t N, int W,
   if (i >= N || !mask[i]) return;
   for (int w = 0; w < 2 * W; ++w) planes[(int64_t)w * N + i] = 0ull;
   meta[i] = 0u;
-}
-
-// ------------------------------------------------------------------ step (full batch, fused write-out)
-// DRAW: the lane draws its own uniformly random legal move (RandomPolicy, policy.py:18-29) instead of reading
-// actions[i] -- mnk_step_random, BASELINE.json config 2 in one launch per ply
-struct MnkDraw {
-  uint64_t seed, step;
-  const uint64_t* step_dev;
-  int64_t env_id0;
-  uint32_t stream_id;
-  int64_t* actions_out;  // optional: the moves played
-};
-
-template <int NW, int CN, int CK, bool DRAW>
-__global__ void __launch_bounds__(256)
-k_step_full(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions, MnkDraw draw, float* rewards,
-            uint8_t* dones, uint8_t* legal_mask, void* obs, int obs_dtype, int32_t* err, uint32_t flags, int vec_ok,
-            int envs_per_block) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
-  const int64_t env0 = (int64_t)blockIdx.x * B;
-  const int64_t i = env0 + tid;
-  const bool emit = (legal_mask != nullptr) || (obs != nullptr);
-  MnkStage st = mnk_stage_carve(lds_raw, g, B);
-  if (emit) mnk_stage_tables(st, g, B, tid, NT);
-  if (tid < B && i < N) {
-    MnkEnv<NW> e;
-    env_load<NW>(e, planes, meta, N, g.W, i);
-    MnkPly ply;
-    if constexpr (DRAW) {
-      const uint64_t step = draw.step + (draw.step_dev ? *draw.step_dev : 0ull);
-      const int a = env_pick_legal<NW, CN>(g, e, mnk_rand_u32(draw.seed, (uint64_t)(draw.env_id0 + i), step, draw.stream_id));
-      if (draw.actions_out) draw.actions_out[i] = a;
-      ply = env_play<NW, CN, CK, true>(g, e, a, false);
-    } else {
-      ply = env_play<NW, CN, CK>(g, e, actions[i], (flags & MNK_STEP_STRICT) != 0);
-    }
-    if ((flags & MNK_STEP_AUTORESET) && ply.done) env_clear<NW>(e);  // :34-44 for the envs of nonzero(done)
-    if (ply.err) mnk_report(err, ply.err, i);
-    else env_store<NW>(e, planes, meta, N, g.W, i);
-    rewards[i] = ply.win ? 1.0f : 0.0f;   // :75-77
-    dones[i] = ply.done ? 1 : 0;          // :79-80
-    if (emit) mnk_stage_put<NW>(st, g, B, tid, e.p[0], e.p[1], false);
-  }
-  if (emit) {
-    const int64_t left = N - env0;
-    const int nb = left < B ? (int)left : B;
-    mnk_write_out<NW, CN, CK>(st, g, B, nb, mnk_obs_slab(obs, obs_dtype, env0, g.C), obs_dtype,
-                              legal_mask ? legal_mask + env0 * g.C : nullptr, vec_ok, tid, NT);
-  }
-}
-
-// step_subset: lane j plays env active_idx[j]; rewards / dones were zero-filled by the launcher
-template <int NW, int CN, int CK>
-__global__ void __launch_bounds__(256)
-k_step_subset(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int64_t* actions,
-              const int64_t* active_idx, int64_t A, float* rewards, uint8_t* dones, int32_t* err,
-              uint32_t flags) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= A) return;
-  int64_t i = active_idx[j];
-  if (i < 0) i += N;
-  if (i < 0 || i >= N) { mnk_report(err, MNK_ERR_ACTION_RANGE, active_idx[j]); return; }
-  MnkEnv<NW> e;
-  env_load<NW>(e, planes, meta, N, g.W, i);
-  MnkPly ply = env_play<NW, CN, CK>(g, e, actions[j], (flags & MNK_STEP_STRICT) != 0);
-  if (ply.err) { mnk_report(err, ply.err, i); return; }
-  env_store<NW>(e, planes, meta, N, g.W, i);
-  rewards[i] = ply.win ? 1.0f : 0.0f;
-  dones[i] = ply.done ? 1 : 0;
-}
-
-// ------------------------------------------------------------------ observe / unpack
-template <int NW, int CN, int CK>
-__global__ void __launch_bounds__(256)
-k_observe(MnkGeom g, const uint64_t* planes, int64_t N, const int64_t* flip_side, void* obs, int obs_dtype,
-          uint8_t* legal_mask, int fix_empty, uint64_t* packed_obs, int vec_ok, int envs_per_block) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
-  const int64_t env0 = (int64_t)blockIdx.x * B;
-  const int64_t i = env0 + tid;
-  MnkStage st = mnk_stage_carve(lds_raw, g, B);
-  mnk_stage_tables(st, g, B, tid, NT);
-  if (tid < B && i < N) {
-    uint32_t p0[NW], p1[NW];
-    plane_load<NW>(p0, planes, N, g.W, i);
-    plane_load<NW>(p1, planes + (int64_t)g.W * N, N, g.W, i);
-    const bool flip = flip_side && flip_side[i] == 1;  // wrapper:104-106
-    if (flip) mnk_stage_put<NW>(st, g, B, tid, p1, p0, fix_empty != 0);
-    else mnk_stage_put<NW>(st, g, B, tid, p0, p1, fix_empty != 0);
-    if (packed_obs) mnk_packed_put<NW>(packed_obs, N, g.W, i, flip ? p1 : p0, flip ? p0 : p1);
-  }
-  if (!obs && !legal_mask) return;  // packed planes only (workgroup-uniform)
-  const int64_t left = N - env0;
-  const int nb = left < B ? (int)left : B;
-  mnk_write_out<NW, CN, CK>(st, g, B, nb, mnk_obs_slab(obs, obs_dtype, env0, g.C), obs_dtype,
-                            legal_mask ? legal_mask + env0 * g.C : nullptr, vec_ok, tid, NT);
 }
 
 // dense f32 -> packed; rare path (the writable env.boards view), one lane per env
@@ -147,94 +51,6 @@ __global__ void k_pack_boards(MnkGeom g, const float* boards, uint64_t* planes, 
     planes[(int64_t)(pl * g.W + cur) * N + i] = word;
     for (int w = cur + 1; w < g.W; ++w) planes[(int64_t)(pl * g.W + w) * N + i] = 0ull;
   }
-}
-
-// ------------------------------------------------------------------ RandomPolicy
-template <int NW, int CN, int CK>
-__global__ void __launch_bounds__(256)
-k_sample_legal(MnkGeom g, const uint64_t* planes, int64_t N, uint64_t seed, uint64_t step, const uint64_t* step_dev,
-               int64_t env_id0, uint32_t stream_id, int64_t* actions) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  if (step_dev) step += *step_dev;  // device-resident part of the step counter (graph replays)
-  MnkEnv<NW> e;
-  plane_load<NW>(e.p[0], planes, N, g.W, i);
-  plane_load<NW>(e.p[1], planes + (int64_t)g.W * N, N, g.W, i);
-  e.meta = 0u;
-  const uint32_t x = mnk_rand_u32(seed, (uint64_t)(env_id0 + i), step, stream_id);
-  actions[i] = env_pick_legal<NW, CN>(g, e, x);
-}
-
-// ------------------------------------------------------------------ records -> RolloutBuffer layout
-template <int NW, int CN, int CK>
-__global__ void __launch_bounds__(256)
-k_unpack_records(MnkGeom g, const uint64_t* rec_planes, const uint32_t* rec_meta, int64_t N, void* obs, int obs_dtype,
-                 uint8_t* masks, int64_t* actions, float* rewards, uint8_t* dones, int vec_ok, int envs_per_block) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
-  const int64_t t = blockIdx.y;
-  const int64_t env0 = (int64_t)blockIdx.x * B;
-  const int64_t i = env0 + tid;
-  const bool emit = obs || masks;
-  MnkStage st = mnk_stage_carve(lds_raw, g, B);
-  if (emit) mnk_stage_tables(st, g, B, tid, NT);
-  if (tid < B && i < N) {
-    const uint32_t mw = rec_meta[t * N + i];
-    if (actions) actions[t * N + i] = (int64_t)(mw & MNK_REC_ACTION_MASK);
-    if (rewards) rewards[t * N + i] = (float)(int8_t)((mw >> MNK_REC_REWARD_SHIFT) & 0xFFu);
-    if (dones) dones[t * N + i] = (uint8_t)((mw >> MNK_REC_DONE_BIT) & 1u);
-    if (emit) {
-      uint32_t p0[NW], p1[NW];
-      // a record is already in the mover's view (mover's words low, other side's high): channel 0 = p0
-      rec_load<NW>(p0, p1, rec_planes + t * g.NW * N, N, g.NW, i);
-      mnk_stage_put<NW>(st, g, B, tid, p0, p1, false);
-    }
-  }
-  if (emit) {
-    const int64_t left = N - env0;
-    const int nb = left < B ? (int)left : B;
-    const int64_t row0 = t * N + env0;
-    mnk_write_out<NW, CN, CK>(st, g, B, nb, mnk_obs_slab(obs, obs_dtype, row0, g.C), obs_dtype,
-                              masks ? masks + row0 * g.C : nullptr, vec_ok, tid, NT);
-  }
-}
-
-// ------------------------------------------------------------------ minibatch gather from packed observations
-// alg/rollout_buffer.py:82-113 (get_data_loader) indexes f32 [T*N, 2, m, n] observations and bool masks with a
-// random permutation -- 729 B read + 729 B written per sample at 9x9.  Here the buffer keeps the packed planes
-// (32 B per sample) and this kernel expands the drawn samples straight into the network's input layout:
-// sample j = flat id idx[j] = t*N + i; lane j fetches its planes (a 32-byte random gather), the workgroup
-// writes its contiguous slab of observations and masks through the LDS stage.
-template <int NW, int CN, int CK>
-__global__ void __launch_bounds__(256)
-k_gather_obs(MnkGeom g, const uint64_t* planes, int64_t T, int64_t N, const int64_t* idx, int64_t B_total, void* obs,
-             int obs_dtype, uint8_t* legal_mask, int fix_empty, int32_t* err, int vec_ok, int envs_per_block) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int B = envs_per_block, NT = blockDim.x, tid = threadIdx.x;
-  const int64_t row0 = (int64_t)blockIdx.x * B;
-  const int64_t j = row0 + tid;
-  MnkStage st = mnk_stage_carve(lds_raw, g, B);
-  mnk_stage_tables(st, g, B, tid, NT);
-  if (tid < B && j < B_total) {
-    int64_t flat = idx[j];
-    if (flat < 0) flat += T * N;
-    uint32_t p0[NW], p1[NW];
-    if (flat < 0 || flat >= T * N) {
-      mnk_report(err, MNK_ERR_ACTION_RANGE, idx[j]);
-#pragma unroll
-      for (int w = 0; w < NW; ++w) p0[w] = p1[w] = 0u;
-    } else {
-      const int64_t t = flat / N, i = flat - t * N;
-      const uint64_t* base = planes + t * 2 * g.W * N;
-      plane_load<NW>(p0, base, N, g.W, i);
-      plane_load<NW>(p1, base + (int64_t)g.W * N, N, g.W, i);
-    }
-    mnk_stage_put<NW>(st, g, B, tid, p0, p1, fix_empty != 0);
-  }
-  const int64_t left = B_total - row0;
-  const int nb = left < B ? (int)left : B;
-  mnk_write_out<NW, CN, CK>(st, g, B, nb, mnk_obs_slab(obs, obs_dtype, row0, g.C), obs_dtype,
-                            legal_mask ? legal_mask + row0 * g.C : nullptr, vec_ok, tid, NT);
 }
 
 // ------------------------------------------------------------------ GAE (alg/rollout_buffer.py:60-80)
@@ -398,9 +214,15 @@ int mnk_observe(const uint64_t* planes, const uint32_t* meta, int64_t N, int m, 
   if (N == 0 || (!obs && !legal_mask && !packed_obs)) return MNK_OK;
   const int B = mnk_block_envs(N);
   const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
-  const size_t lds = mnk_stage_bytes(g.NW, g.C, B, g.n, g.k);
-  const dim3 grid((unsigned)((N + B - 1) / B));
-  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_observe), grid, dim3(mnk_block_threads(obs != nullptr)), lds, (hipStream_t)stream, g, planes, N,
+  const dim3 grid((unsigned)((N + B - 1) / B)), block(mnk_block_threads(obs != nullptr));
+  hipStream_t s = (hipStream_t)stream;
+  if (hipFunction_t fn = mnk_jit_api_function(g, MNK_JK_OBSERVE, N, s)) {  // the board's own variant (mnk_jit.hip)
+    mnk_module_launch(&k_observe<2, 0, 0>, fn, grid, block, mnk_stage_bytes(g.NW, g.C, B, g.n, mnk_packed_cells(g.n, g.C)), s,
+                      g, planes, N, flip_side, obs, obs_dtype, legal_mask, fix_empty_mask, packed_obs, vec_ok, B);
+    return mnk_launch_status("observe (run-time specialised)");
+  }
+  const size_t lds = mnk_stage_bytes(g.NW, g.C, B, g.n, mnk_geom_packed(g.n, g.k, g.NW, g.C));
+  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_observe), grid, block, lds, s, g, planes, N,
                                          flip_side, obs, obs_dtype, legal_mask, fix_empty_mask, packed_obs, vec_ok, B));
   return mnk_launch_status("observe");
 }
@@ -429,15 +251,21 @@ static int mnk_launch_step_full(const MnkGeom& g, uint64_t* planes, uint32_t* me
   const int B = mnk_block_envs(N);
   const bool emit = legal_mask || obs;
   const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
-  const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, g.k) : 0;
-  const dim3 grid((unsigned)((N + B - 1) / B));
+  const dim3 grid((unsigned)((N + B - 1) / B)), block(mnk_block_threads(obs != nullptr));
   const MnkDraw none = {0, 0, nullptr, 0, 0, nullptr};
+  if (hipFunction_t fn = mnk_jit_api_function(g, draw ? MNK_JK_STEP_DRAW : MNK_JK_STEP, N, s)) {
+    const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, mnk_packed_cells(g.n, g.C)) : 0;
+    mnk_module_launch(&k_step_full<2, 0, 0, false>, fn, grid, block, lds, s, g, planes, meta, N, actions, draw ? *draw : none,
+                      rewards, dones, legal_mask, obs, obs_dtype, err, flags, vec_ok, B);
+    return mnk_launch_status(draw ? "step_random (run-time specialised)" : "step (run-time specialised)");
+  }
+  const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, mnk_geom_packed(g.n, g.k, g.NW, g.C)) : 0;
   if (draw)
-    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_full<NW, CN, CK, true>), grid, dim3(mnk_block_threads(obs != nullptr)), lds, s,
+    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_full<NW, CN, CK, true>), grid, block, lds, s,
                                        g, planes, meta, N, actions, *draw, rewards, dones, legal_mask, obs, obs_dtype, err,
                                        flags, vec_ok, B));
   else
-    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_full<NW, CN, CK, false>), grid, dim3(mnk_block_threads(obs != nullptr)), lds, s,
+    MNK_DISPATCH(g, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_full<NW, CN, CK, false>), grid, block, lds, s,
                                        g, planes, meta, N, actions, none, rewards, dones, legal_mask, obs, obs_dtype, err,
                                        flags, vec_ok, B));
   return mnk_launch_status(draw ? "step_random" : "step");
@@ -478,8 +306,12 @@ int mnk_step(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, c
   if (A > 0) {
     const int B = 64;
     const dim3 grid((unsigned)((A + B - 1) / B));
-    MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_step_subset), grid, dim3(B), 0, s, g, planes, meta, N, actions,
-                                           active_idx, A, rewards, dones, err, flags));
+    if (hipFunction_t fn = mnk_jit_api_function(g, MNK_JK_STEP_SUBSET, A, s))
+      mnk_module_launch(&k_step_subset<2, 0, 0>, fn, grid, dim3(B), 0, s, g, planes, meta, N, actions, active_idx, A, rewards,
+                        dones, err, flags);
+    else
+      MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_step_subset), grid, dim3(B), 0, s, g, planes, meta, N, actions,
+                                             active_idx, A, rewards, dones, err, flags));
     rc = mnk_launch_status("step_subset");
     if (rc != MNK_OK) return rc;
   }
@@ -496,8 +328,12 @@ int mnk_sample_legal(const uint64_t* planes, int64_t N, int m, int n, uint64_t s
   if (N == 0) return MNK_OK;
   const int B = 64;
   const dim3 grid((unsigned)((N + B - 1) / B));
-  MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_sample_legal), grid, dim3(B), 0, (hipStream_t)stream, g, planes, N, seed,
-                                         step, step_dev, env_id0, (uint32_t)stream_id, actions));
+  if (hipFunction_t fn = mnk_jit_api_function(g, MNK_JK_SAMPLE_LEGAL, N, (hipStream_t)stream))
+    mnk_module_launch(&k_sample_legal<2, 0, 0>, fn, grid, dim3(B), 0, (hipStream_t)stream, g, planes, N, seed, step, step_dev,
+                      env_id0, (uint32_t)stream_id, actions);
+  else
+    MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_sample_legal), grid, dim3(B), 0, (hipStream_t)stream, g, planes, N, seed,
+                                           step, step_dev, env_id0, (uint32_t)stream_id, actions));
   return mnk_launch_status("sample_legal");
 }
 
@@ -512,7 +348,8 @@ int mnk_selfplay_pre(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, 
   if (rc != MNK_OK) return rc;
   if (!actions) return MNK_EINVAL;
   if (N == 0) return MNK_OK;
-  MNK_DISPATCH(a.g, mnk_launch_sp<MNK_SP_PRE, NW, CN, CK, NoDraw>(a, actions, MnkSample{}, (hipStream_t)stream));
+  if (!mnk_launch_sp_jit<MNK_SP_PRE>(a, actions, MnkSample{}, (hipStream_t)stream))
+    MNK_DISPATCH(a.g, mnk_launch_sp<MNK_SP_PRE, NW, CN, CK, NoDraw>(a, actions, MnkSample{}, (hipStream_t)stream));
   return mnk_launch_status("selfplay_pre");
 }
 
@@ -526,7 +363,8 @@ int mnk_selfplay_post(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n,
   if (rc != MNK_OK) return rc;
   if (!opp_actions) return MNK_EINVAL;
   if (N == 0) return MNK_OK;
-  MNK_DISPATCH(a.g, mnk_launch_sp<MNK_SP_POST, NW, CN, CK, NoDraw>(a, opp_actions, MnkSample{}, (hipStream_t)stream));
+  if (!mnk_launch_sp_jit<MNK_SP_POST>(a, opp_actions, MnkSample{}, (hipStream_t)stream))
+    MNK_DISPATCH(a.g, mnk_launch_sp<MNK_SP_POST, NW, CN, CK, NoDraw>(a, opp_actions, MnkSample{}, (hipStream_t)stream));
   return mnk_launch_status("selfplay_post");
 }
 
@@ -543,7 +381,8 @@ int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m,
   if (rc != MNK_OK) return rc;
   if (!actions) return MNK_EINVAL;
   if (N == 0) return MNK_OK;
-  MNK_DISPATCH(a.g, mnk_launch_sp<MNK_SP_STEP_RANDOM, NW, CN, CK, NoDraw>(a, actions, MnkSample{}, (hipStream_t)stream));
+  if (!mnk_launch_sp_jit<MNK_SP_STEP_RANDOM>(a, actions, MnkSample{}, (hipStream_t)stream))
+    MNK_DISPATCH(a.g, mnk_launch_sp<MNK_SP_STEP_RANDOM, NW, CN, CK, NoDraw>(a, actions, MnkSample{}, (hipStream_t)stream));
   return mnk_launch_status("selfplay_step_random");
 }
 
@@ -562,8 +401,14 @@ int mnk_unpack_records(const uint64_t* rec_planes, const uint32_t* rec_meta, int
   const bool obs_vec = aligned16(obs) && ((N * 2 * g.C * mnk_obs_bytes(obs_dtype)) % 16 == 0);
   const bool mask_vec = aligned16(masks) && ((N * g.C) % 16 == 0);
   const int vec_ok = (obs_vec ? 1 : 0) | (mask_vec ? 2 : 0);
-  const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, g.k) : 0;
   const dim3 grid((unsigned)((N + B - 1) / B), (unsigned)T);
+  if (hipFunction_t fn = mnk_jit_api_function(g, MNK_JK_UNPACK_RECORDS, N * (int64_t)T, (hipStream_t)stream)) {
+    const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, mnk_packed_cells(g.n, g.C)) : 0;
+    mnk_module_launch(&k_unpack_records<2, 0, 0>, fn, grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, rec_planes,
+                      rec_meta, N, obs, obs_dtype, masks, actions, rewards, dones, vec_ok, B);
+    return mnk_launch_status("unpack_records (run-time specialised)");
+  }
+  const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, mnk_geom_packed(g.n, g.k, g.NW, g.C)) : 0;
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_unpack_records), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, rec_planes,
                                          rec_meta, N, obs, obs_dtype, masks, actions, rewards, dones, vec_ok, B));
   return mnk_launch_status("unpack_records");
@@ -578,8 +423,14 @@ int mnk_gather_obs(const uint64_t* planes, int64_t T, int64_t N, int m, int n, c
   if (B == 0 || (!obs && !legal_mask)) return MNK_OK;
   const int E = mnk_block_envs(B);
   const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
-  const size_t lds = mnk_stage_bytes(g.NW, g.C, E, g.n, g.k);
   const dim3 grid((unsigned)((B + E - 1) / E));
+  if (hipFunction_t fn = mnk_jit_api_function(g, MNK_JK_GATHER_OBS, B, (hipStream_t)stream)) {
+    mnk_module_launch(&k_gather_obs<2, 0, 0>, fn, grid, dim3(mnk_block_threads()),
+                      mnk_stage_bytes(g.NW, g.C, E, g.n, mnk_packed_cells(g.n, g.C)), (hipStream_t)stream, g, planes, T, N, idx, B,
+                      obs, obs_dtype, legal_mask, fix_empty_mask, err, vec_ok, E);
+    return mnk_launch_status("gather_obs (run-time specialised)");
+  }
+  const size_t lds = mnk_stage_bytes(g.NW, g.C, E, g.n, mnk_geom_packed(g.n, g.k, g.NW, g.C));
   MNK_DISPATCH(g, hipLaunchKernelGGL(MNK_K(k_gather_obs), grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g,
                                      planes, T, N, idx, B, obs, obs_dtype, legal_mask, fix_empty_mask, err, vec_ok, E));
   return mnk_launch_status("gather_obs");

@@ -81,7 +81,7 @@ void dispatch_sample(const void* logits, const uint8_t* mask, int64_t N, int C, 
                      float* logp, hipStream_t s) {
 #define MNK_SAMPLE(LPRv, Kv, EXv) \
   launch_sample<LPRv, Kv, EXv, LT>(logits, mask, N, C, seed, seed_dev, step, step_dev, env_id0, deterministic, actions, logp, s)
-#define MNK_SAMPLE_SHAPE(Cv) MNK_SAMPLE(Shape<Cv>::LPR, Shape<Cv>::K, true)
+#define MNK_SAMPLE_SHAPE(Cv) MNK_SAMPLE(Shape<Cv>::LPR, Shape<Cv>::K, Shape<Cv>::EXACT)
   // lanes per row x cells per lane, by measurement (9x9: 4 lanes per row 7.1 us, 8 lanes per row 9.9 us; profiles/r02_api_kernels.md)
   // (the shapes of these five live in mnk_draw.h: the step kernels with a folded-in draw must use the same ones)
   if (C == 81) MNK_SAMPLE_SHAPE(81);             // 9x9
@@ -89,11 +89,13 @@ void dispatch_sample(const void* logits, const uint8_t* mask, int64_t N, int C, 
   else if (C == 169) MNK_SAMPLE_SHAPE(169);      // 13x13
   else if (C == 225) MNK_SAMPLE_SHAPE(225);      // 15x15
   else if (C == 361) MNK_SAMPLE_SHAPE(361);      // 19x19
-  else if (C <= 32) MNK_SAMPLE(4, 8, false);
-  else if (C <= 96) MNK_SAMPLE(8, 12, false);
-  else if (C <= 256) MNK_SAMPLE(16, 16, false);
-  else if (C <= 512) MNK_SAMPLE(32, 16, false);  // up to 512 cells (22x22)
-  else MNK_SAMPLE(32, 32, false);                // up to 1 024 cells (25x25, 31x31)
+  // (the generic shapes: mnk_draw::Shape's primary template names the same ones, for the run-time specialised step
+  // kernels that fold this draw in)
+  else if (C <= 32) MNK_SAMPLE_SHAPE(32);
+  else if (C <= 96) MNK_SAMPLE_SHAPE(96);
+  else if (C <= 256) MNK_SAMPLE_SHAPE(256);
+  else if (C <= 512) MNK_SAMPLE_SHAPE(512);      // up to 512 cells (22x22)
+  else MNK_SAMPLE_SHAPE(1024);                   // up to 1 024 cells (25x25, 31x31)
 #undef MNK_SAMPLE_SHAPE
 #undef MNK_SAMPLE
 }

@@ -2,7 +2,7 @@
 // C ABI).  One translation unit per entry point (mnk_selfplay_{pre,post,step}_logits.hip) so that the 15 kernel variants of
 // each -- five boards x {f32, bf16, no logits} -- compile in parallel.
 #pragma once
-#include "mnk_selfplay_kernels.h"
+#include "mnk_selfplay_host.h"
 
 inline int mnk_sample_args_ok(const MnkSample& sa, int64_t N, int C) {
   if (!sa.mask || !sa.actions || C < 1 || C > 1024 || N > 0x7fffffffLL) return MNK_EINVAL;
@@ -11,10 +11,12 @@ inline int mnk_sample_args_ok(const MnkSample& sa, int64_t N, int C) {
 }
 
 // Launches kernel WHICH with the draw folded in when the board has a compile-time draw shape (3x3x3, 9x9x5, 13x13x5,
-// 15x15x5, 19x19x5: the boards the reference trains on and the usual Gomoku sizes); false = the caller takes two launches.
+// 15x15x5, 19x19x5: the boards the reference trains on and the usual Gomoku sizes) or a run-time compiled variant of its own
+// (mnk_jit.hip: any other board, any row width); false = the caller takes two launches.
 template <int WHICH>
 inline bool mnk_launch_sp_fused(const MnkSpArgs& a, const MnkSample& sa, hipStream_t s) {
   const MnkGeom& g = a.g;
+  if (mnk_launch_sp_jit<WHICH>(a, nullptr, sa, s)) return true;  // a board without a built-in variant, once it is hot
   if (g.m != g.n) return false;
   const int lt = !sa.logits ? 2 : (sa.logits_dtype == MNK_LOGITS_BF16 ? 1 : 0);
 #define MNK_FUSED(NWv, CNv, CKv, Cv)                                                                            \

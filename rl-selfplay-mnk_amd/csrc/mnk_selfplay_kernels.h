@@ -17,16 +17,8 @@
 // Instantiations of the Draw forms live in mnk_selfplay_draw.hip (boards 3x3, 9x9, 13x13, 15x15, 19x19 x f32 / bf16 / no
 // logits); other boards take two launches behind the same C-ABI entry points.
 #pragma once
-#include "mnk_host.h"
+#include "mnk_api_kernels.h"
 #include "mnk_draw.h"
-
-// the view (channel 0, channel 1) of env i as packed planes u64[2][W][N]: what PackedRolloutBuffer stores
-template <int NW>
-__device__ __forceinline__ void mnk_packed_put(uint64_t* packed, int64_t N, int W, int64_t i, const uint32_t (&ch0)[NW],
-                                               const uint32_t (&ch1)[NW]) {
-  plane_store<NW>(ch0, packed, N, W, i);
-  plane_store<NW>(ch1, packed + (int64_t)W * N, N, W, i);
-}
 
 // ------------------------------------------------------------------ the draw folded into a step kernel
 struct NoDraw {
@@ -38,6 +30,7 @@ struct Draw {
   static constexpr bool ON = true;
   using LT = LT_;
   static constexpr int C = CC, LPR = mnk_draw::Shape<CC>::LPR, K = mnk_draw::Shape<CC>::K;
+  static constexpr bool EXACT = mnk_draw::Shape<CC>::EXACT;
 };
 
 // LDS the draw needs behind the write-out stage: int act[B] | float slab[rows * C + 2 VE] | float u[rows], rows = NT / LPR
@@ -73,7 +66,7 @@ __device__ __forceinline__ int* mnk_draw_block(const MnkSample& sa, unsigned cha
     __syncthreads();
     const bool live = r < rows_here;
     const float* lrow = lds_l + (e0 & (VE - 1)) + (size_t)(live ? r : 0) * C;  // idle groups redo row 0
-    const Drawn d = draw_row<LPR, D::K, true>(lrow, C, lds_u[live ? r : 0], sa.deterministic, tid);
+    const Drawn d = draw_row<LPR, D::K, D::EXACT>(lrow, C, lds_u[live ? r : 0], sa.deterministic, tid);
     if (sub == 0 && live) {
       lds_act[p0 + r] = d.chosen;
       sa.actions[row0 + r] = d.chosen;
@@ -163,7 +156,7 @@ k_selfplay_pre(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const int
   const int nb = left < B ? (int)left : B;
   const bool emit = opp_obs || opp_mask;
   MnkStage st = mnk_stage_carve(lds_raw, g, B);
-  if (emit) mnk_stage_tables(st, g, B, tid, NT);
+  if (emit) mnk_stage_tables<CN>(st, g, B, tid, NT);
   const int* drawn = nullptr;
   if constexpr (DRAW::ON) drawn = mnk_draw_block<DRAW>(sa, lds_raw + stage_span, env0, nb, N, B, tid, NT);
   if (tid < B && i < N) {
@@ -210,7 +203,7 @@ k_selfplay_post(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, const in
   const int nb = left < B ? (int)left : B;
   const bool emit = obs || legal_mask;
   MnkStage st = mnk_stage_carve(lds_raw, g, B);
-  if (emit) mnk_stage_tables(st, g, B, tid, NT);
+  if (emit) mnk_stage_tables<CN>(st, g, B, tid, NT);
   if (ep.stats) {
     if (tid < MNK_STATS_COUNTERS) lds_ep[tid] = 0u;
     __syncthreads();
@@ -275,7 +268,7 @@ k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, c
   const int nb = left < B ? (int)left : B;
   const bool emit = obs || legal_mask;
   MnkStage st = mnk_stage_carve(lds_raw, g, B);
-  if (emit) mnk_stage_tables(st, g, B, tid, NT);
+  if (emit) mnk_stage_tables<CN>(st, g, B, tid, NT);
   if (ep.stats) {
     if (tid < MNK_STATS_COUNTERS) lds_ep[tid] = 0u;
     __syncthreads();
@@ -320,111 +313,4 @@ k_selfplay_step_random(MnkGeom g, uint64_t* planes, uint32_t* meta, int64_t N, c
     __syncthreads();
   }
   if (ep.stats) mnk_ep_flush(ep, lds_ep);
-}
-
-// ------------------------------------------------------------------ launchers shared by the two translation units
-// everything one of the three step kernels takes besides the moves
-struct MnkSpArgs {
-  MnkGeom g;
-  uint64_t* planes;
-  uint32_t* meta;
-  int64_t N;
-  uint8_t* pending;          // pre: read; post / step_random: written
-  int64_t* agent_side;
-  const int64_t* forced_side;
-  uint64_t seed, step;
-  const uint64_t* step_dev;
-  int64_t env_id0;
-  float* rewards;
-  uint8_t* terminated;
-  uint8_t* sp_flags;         // pre: written; post: read
-  void* obs;                 // pre: the opponent's view; post / step_random: the agent's
-  int obs_dtype;
-  uint8_t* mask;
-  uint64_t* packed_obs;
-  int32_t* err;
-  MnkEpisodes ep;
-  uint32_t flags;
-};
-
-enum { MNK_SP_PRE = 0, MNK_SP_POST = 1, MNK_SP_STEP_RANDOM = 2 };
-
-// argument checks + MnkSpArgs of the three entry points (shared by their actions and their logits forms)
-inline int mnk_sp_args_pre(MnkSpArgs* a, uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const uint8_t* pending,
-                           int64_t* agent_side, const int64_t* forced_side, uint64_t seed, uint64_t step,
-                           const uint64_t* step_dev, int64_t env_id0, float* rewards, uint8_t* terminated, uint8_t* sp_flags,
-                           void* opp_obs, int obs_dtype, uint8_t* opp_mask, int32_t* err, uint32_t flags) {
-  memset(a, 0, sizeof(*a));
-  int rc = mnk_check_geom(m, n, k, &a->g);
-  if (rc != MNK_OK) return rc;
-  if (!planes || !meta || !pending || !agent_side || !rewards || !terminated || !sp_flags || N < 0 || !mnk_obs_dtype_ok(obs_dtype))
-    return MNK_EINVAL;
-  a->planes = planes; a->meta = meta; a->N = N; a->pending = const_cast<uint8_t*>(pending); a->agent_side = agent_side;
-  a->forced_side = forced_side; a->seed = seed; a->step = step; a->step_dev = step_dev; a->env_id0 = env_id0;
-  a->rewards = rewards; a->terminated = terminated; a->sp_flags = sp_flags; a->obs = opp_obs; a->obs_dtype = obs_dtype;
-  a->mask = opp_mask; a->err = err; a->flags = flags;
-  return MNK_OK;
-}
-
-inline int mnk_sp_args_post(MnkSpArgs* a, uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const uint8_t* sp_flags,
-                            const int64_t* agent_side, float* rewards, uint8_t* terminated, uint8_t* pending, void* obs,
-                            int obs_dtype, uint8_t* legal_mask, uint64_t* packed_obs, int32_t* err, float* ep_return,
-                            int32_t* ep_length, int64_t* ep_stats, uint32_t flags) {
-  memset(a, 0, sizeof(*a));
-  int rc = mnk_check_geom(m, n, k, &a->g);
-  if (rc != MNK_OK) return rc;
-  if (!planes || !meta || !sp_flags || !agent_side || !rewards || !terminated || !pending || N < 0 || !mnk_obs_dtype_ok(obs_dtype))
-    return MNK_EINVAL;
-  if (ep_stats && (!ep_return || !ep_length)) return MNK_EINVAL;
-  a->planes = planes; a->meta = meta; a->N = N; a->pending = pending; a->agent_side = const_cast<int64_t*>(agent_side);
-  a->rewards = rewards; a->terminated = terminated; a->sp_flags = const_cast<uint8_t*>(sp_flags); a->obs = obs;
-  a->obs_dtype = obs_dtype; a->mask = legal_mask; a->packed_obs = packed_obs; a->err = err;
-  a->ep = MnkEpisodes{ep_return, ep_length, (unsigned long long*)ep_stats}; a->flags = flags;
-  return MNK_OK;
-}
-
-inline int mnk_sp_args_step_random(MnkSpArgs* a, uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, uint8_t* pending,
-                                   int64_t* agent_side, const int64_t* forced_side, uint64_t seed, uint64_t step,
-                                   const uint64_t* step_dev, int64_t env_id0, float* rewards, uint8_t* terminated, void* obs,
-                                   int obs_dtype, uint8_t* legal_mask, uint64_t* packed_obs, int32_t* err, float* ep_return,
-                                   int32_t* ep_length, int64_t* ep_stats, uint32_t flags) {
-  memset(a, 0, sizeof(*a));
-  int rc = mnk_check_geom(m, n, k, &a->g);
-  if (rc != MNK_OK) return rc;
-  if (!planes || !meta || !pending || !agent_side || !rewards || !terminated || N < 0 || !mnk_obs_dtype_ok(obs_dtype))
-    return MNK_EINVAL;
-  if (ep_stats && (!ep_return || !ep_length)) return MNK_EINVAL;
-  a->planes = planes; a->meta = meta; a->N = N; a->pending = pending; a->agent_side = agent_side; a->forced_side = forced_side;
-  a->seed = seed; a->step = step; a->step_dev = step_dev; a->env_id0 = env_id0; a->rewards = rewards;
-  a->terminated = terminated; a->obs = obs; a->obs_dtype = obs_dtype; a->mask = legal_mask; a->packed_obs = packed_obs;
-  a->err = err; a->ep = MnkEpisodes{ep_return, ep_length, (unsigned long long*)ep_stats}; a->flags = flags;
-  return MNK_OK;
-}
-
-// one launch of kernel WHICH in its DRAW form; `moves` = the actions array of the NoDraw form
-template <int WHICH, int NW, int CN, int CK, typename DRAW>
-inline void mnk_launch_sp(const MnkSpArgs& a, const int64_t* moves, const MnkSample& sa, hipStream_t s) {
-  const int B = mnk_block_envs(a.N), NT = mnk_block_threads();
-  const bool emit = a.obs || a.mask;
-  const int vec_ok = (aligned16(a.obs) ? 1 : 0) | (aligned16(a.mask) ? 2 : 0);
-  const size_t stage = emit ? mnk_stage_bytes(a.g.NW, a.g.C, B, a.g.n, a.g.k) : 0;
-  size_t lds = stage;
-  int span = 0;
-  if constexpr (DRAW::ON) {
-    span = (int)mnk_stage_span(stage);
-    lds = (size_t)span + mnk_draw_lds_bytes<DRAW>(B, NT);
-  }
-  const dim3 grid((unsigned)((a.N + B - 1) / B)), block(NT);
-  if constexpr (WHICH == MNK_SP_PRE)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_selfplay_pre<NW, CN, CK, DRAW>), grid, block, lds, s, a.g, a.planes, a.meta, a.N, moves, sa,
-                       a.pending, a.agent_side, a.forced_side, a.seed, a.step, a.step_dev, a.env_id0, a.rewards, a.terminated,
-                       a.sp_flags, a.obs, a.obs_dtype, a.mask, a.err, a.flags, vec_ok, B, span);
-  else if constexpr (WHICH == MNK_SP_POST)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_selfplay_post<NW, CN, CK, DRAW>), grid, block, lds, s, a.g, a.planes, a.meta, a.N, moves, sa,
-                       a.sp_flags, a.agent_side, a.rewards, a.terminated, a.pending, a.obs, a.obs_dtype, a.mask, a.packed_obs,
-                       a.err, a.ep, a.flags, vec_ok, B, span);
-  else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_selfplay_step_random<NW, CN, CK, DRAW>), grid, block, lds, s, a.g, a.planes, a.meta, a.N,
-                       moves, sa, a.pending, a.agent_side, a.forced_side, a.seed, a.step, a.step_dev, a.env_id0, a.rewards,
-                       a.terminated, a.obs, a.obs_dtype, a.mask, a.packed_obs, a.err, a.ep, a.flags, vec_ok, B, span);
 }

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MNK_HIP_LIB: another build of the same library (A/B experiments with compile-time options); default: the in-tree build
 LIB_PATH = os.environ.get("MNK_HIP_LIB") or os.path.join(_HERE, "libmnk_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 MNK_OK = 0
 ERR_NONE, ERR_ACTION_RANGE, ERR_ILLEGAL_MOVE = 0, 1, 2
@@ -24,6 +24,10 @@ COMM_ID_BYTES = 128
 SP_NEED_OPP, SP_WAS_RESET = 1, 2
 STREAM_MOVE, STREAM_OPP, STREAM_SIDE, STREAM_SAMPLE = 0, 1, 2, 3
 STATS_REPLICAS, STATS_STRIDE, STATS_COUNTERS = 64, 8, 5
+# run-time specialised API kernels (MNK_JIT_API_* of include/mnk_hip.h): bit numbers for jit_prepare()
+(JIT_API_STEP, JIT_API_STEP_DRAW, JIT_API_STEP_SUBSET, JIT_API_OBSERVE, JIT_API_SAMPLE_LEGAL, JIT_API_UNPACK_RECORDS,
+ JIT_API_GATHER_OBS, JIT_API_SP_PRE, JIT_API_SP_POST, JIT_API_SP_STEP, JIT_API_SP_DRAW) = range(11)
+JIT_API_COUNT = 19
 REC_ACTION_MASK, REC_REWARD_SHIFT, REC_DONE_BIT, REC_SIDE_BIT = 0xFFFF, 16, 24, 25
 
 _vp, _i, _i64, _u64, _u32, _f = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint32,
@@ -72,6 +76,9 @@ SIGNATURES = {
     "mnk_jit_compile_rollout": [_i, _i, _i, _i, _i],
     "mnk_jit_compile_kernel": [_i, _i, _i, _i, _i, _i],
     "mnk_jit_last_error": [],
+    "mnk_jit_compile_api": [_i, _i, _i, _i],
+    "mnk_jit_prepare": [_i, _i, _i, _i64],
+    "mnk_jit_api_ready": [_i, _i, _i, _i],
     "mnk_comm_unique_id": [_vp],
     "mnk_comm_init": [_vp, _vp, _i, _i],
     "mnk_comm_destroy": [_vp],
@@ -114,7 +121,7 @@ def load():
         fn.argtypes = argtypes
         if name in ("mnk_last_launch_error", "mnk_comm_last_error", "mnk_jit_last_error"):
             fn.restype = ctypes.c_char_p
-        elif name in ("mnk_jit_compile_rollout", "mnk_jit_compile_kernel"):
+        elif name in ("mnk_jit_compile_rollout", "mnk_jit_compile_kernel", "mnk_jit_compile_api"):
             fn.restype = ctypes.c_int64
         else:
             fn.restype = ctypes.c_int
@@ -185,6 +192,35 @@ def reload_config() -> None:
     """The library reads its developer knobs (MNK_ROLLOUT_PAIR / _FORM / _SADDR, MNK_JIT, MNK_EMIT_ENVS / _THREADS) from
     the environment once; call this after changing ``os.environ`` to make it read them again."""
     call("mnk_reload_config")
+
+
+def jit_api_draw_kind(which: int, logits_dtype=None) -> int:
+    """MNK_JIT_API_* number of a self-play step kernel with the draw folded in: ``which`` 0 pre / 1 post / 2
+    step_random; ``logits_dtype`` torch.float32, torch.bfloat16 or None (no logits: uniform over the mask)"""
+    lt = 2 if logits_dtype is None else (1 if logits_dtype == torch.bfloat16 else 0)
+    return JIT_API_SP_DRAW + 3 * lt + which
+
+
+def jit_prepare(m: int, n: int, k: int, kinds=None) -> int:
+    """Compile and load NOW the board's own variants of the API kernels in ``kinds`` (iterable of JIT_API_* numbers;
+    None: of every kernel launched on this board so far) instead of when they get hot -- before a hipGraph capture,
+    where nothing can be compiled: warm up, ``jit_prepare(m, n, k)``, capture.  Returns how many are ready; 0 for
+    boards with a built-in variant (3x3x3, 9x9x5, 13x13x5, 15x15x5, 19x19x5) or with MNK_JIT_API / MNK_JIT = 0."""
+    mask = 0
+    for kind in (kinds if kinds is not None else ()):
+        mask |= 1 << int(kind)
+    if kinds is not None and mask == 0:
+        return 0
+    lib = load()
+    rc = lib.mnk_jit_prepare(m, n, k, mask)
+    if rc < 0:
+        raise MnkHipError(f"mnk_jit_prepare({m}, {n}, {k}): {_STATUS.get(rc, rc)}: " + (lib.mnk_jit_last_error() or b"").decode())
+    return rc
+
+
+def jit_api_ready(m: int, n: int, k: int, kind: int) -> bool:
+    """is the board's own variant of API kernel ``kind`` (JIT_API_*) loaded on the current device?"""
+    return bool(load().mnk_jit_api_ready(m, n, k, int(kind)))
 
 
 def state_words(m, n):

@@ -119,6 +119,14 @@ import torch
 import mnk_hip
 
 
+def _prepare_board_kernels(env) -> None:
+    """Between warm-up and capture: on a board without a built-in kernel variant the library compiles the board's own
+    variant of an API kernel once that kernel is hot -- but never under a capture, so a graph captured earlier would
+    replay the generic kernels for good.  The warm-up has launched exactly the kernels the capture will: compile those
+    now (about a second each, once per board and process; nothing to do on 3x3x3, 9x9x5, 13x13x5, 15x15x5, 19x19x5)."""
+    mnk_hip.jit_prepare(env.m, env.n, env.k)
+
+
 class GraphedAgentStep:
     def __init__(self, wrapper, net, seed=None):
         self.wrapper, self.net = wrapper, net
@@ -177,6 +185,7 @@ class GraphedAgentStep:
                 self._body(self.cur)
                 self.cur ^= 1
         torch.cuda.current_stream(self.dev).wait_stream(side)
+        _prepare_board_kernels(w.env)
         for src in (0, 1):
             self.graphs[src] = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graphs[src]):
@@ -327,6 +336,7 @@ class GraphedRollout:
         with torch.cuda.stream(side):  # one real rollout as the warm-up torch.cuda.graph asks for
             self._body()
         torch.cuda.current_stream(self.dev).wait_stream(side)
+        _prepare_board_kernels(w.env)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._body()

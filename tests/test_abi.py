@@ -107,12 +107,31 @@ def test_rollout_kernel_specialises_at_run_time_without_a_gpu(lib):
     assert handle.mnk_jit_compile_kernel(12, 12, 5, 1, 0, 3) == -1
 
 
+def test_api_kernels_specialise_at_run_time_without_a_gpu(lib):
+    """ABI 6: hiprtc instantiates the API-level kernel templates (csrc/mnk_api_kernels.h, mnk_selfplay_kernels.h: the text
+    hipcc compiles, embedded in the library) with a board's own geometry -- step, observe, the records / gather write-outs,
+    the three self-play step kernels with and without the folded-in draw (any row width).  Compiling needs no GPU."""
+    handle = lib.load()
+    boards = {(12, 12, 5): range(lib.JIT_API_COUNT),           # every kind once
+              (6, 7, 4): (lib.JIT_API_STEP, lib.JIT_API_SP_STEP, lib.jit_api_draw_kind(1, None)),   # 2 words per plane
+              (5, 5, 4): (lib.JIT_API_STEP_DRAW, lib.JIT_API_OBSERVE),                              # 1 word per plane
+              (10, 33, 5): (lib.JIT_API_SP_POST, lib.JIT_API_UNPACK_RECORDS),    # rows of more than 31 cells: table write-out
+              (25, 25, 5): (lib.JIT_API_SP_STEP, lib.jit_api_draw_kind(2, __import__("torch").bfloat16))}  # 21 words, 625 cells
+    for (m, n, k), kinds in boards.items():
+        for kind in kinds:
+            size = handle.mnk_jit_compile_api(m, n, k, kind)
+            assert size > 4096, (m, n, k, kind, (handle.mnk_jit_last_error() or b"").decode())
+    assert handle.mnk_jit_compile_api(12, 12, 5, lib.JIT_API_COUNT) == -1   # no such kernel
+    assert handle.mnk_jit_compile_api(12, 12, 5, -1) == -1
+    assert handle.mnk_jit_compile_api(40, 40, 5, 0) == -2                   # beyond the packed layout
+
+
 def test_header_is_plain_c(tmp_path):
     """include/mnk_hip.h is a C ABI: it must compile as C99 (a cgo / JNI / plain C host includes it as is) and as C++."""
     import subprocess
 
     src = tmp_path / "hdr.c"
-    src.write_text('#include "mnk_hip.h"\nint main(void) { return MNK_ABI_VERSION == 5 ? 0 : 1; }\n')
+    src.write_text('#include "mnk_hip.h"\nint main(void) { return MNK_ABI_VERSION == 6 ? 0 : 1; }\n')
     inc = os.path.join(ROOT, "include")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)], check=True)
     subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)], check=True)
@@ -131,5 +150,5 @@ def test_a_plain_c_host_links_against_the_library():
     res = subprocess.run([exe, "--abi"], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr
     got = dict(kv.split("=") for kv in res.stdout.split())
-    assert got == {"abi": "5", "header_abi": "5", "words_9x9": "2", "record_words_9x9": "3", "words_19x19": "6",
+    assert got == {"abi": "6", "header_abi": "6", "words_9x9": "2", "record_words_9x9": "3", "words_19x19": "6",
                    "supported_9x9x5": "1", "supported_2x2x3": "0"}

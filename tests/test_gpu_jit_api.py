@@ -1,0 +1,274 @@
+"""GPU: the API-level kernels specialised at run time (ABI 6, csrc/mnk_jit.hip).
+
+The reference takes any board (env/torch_vector_mnk_env.py:9); the kernels behind ``env.step`` / ``observe`` /
+``wrapper.step`` ... have compile-time geometry for five boards only, every other board used to stay on generic code for
+good.  Now hiprtc instantiates the same kernel templates with the board's own geometry once a kernel is hot (or at the
+first launch with ``MNK_JIT_API=1``), which also moves the board to the packed write-out and folds the masked draw into
+the self-play step kernels for any row width.  The results must not change: the differential fuzzers of
+test_gpu_fuzz.py and the folded-draw parity test of test_gpu_fused_draw.py run here with every API kernel specialised
+from its first launch, on boards with 1 ... 21 words per plane, rows wider than 31 cells (table write-out on compile-time
+geometry) and non-square shapes; then the switch itself: generic -> specialised in the middle of a game, nothing
+compiled under a hipGraph capture, ``jit_prepare`` before one."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import test_gpu_fused_draw as fd
+import test_gpu_fuzz as fz
+import test_gpu_sink as sk
+from oracle.env_torch import OracleVectorEnv
+from oracle.policies import LowestLegalPolicy
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+hip = fz.hip  # the module-scoped fixture of the fuzzers (env, wrapper, rollout, binding)
+
+
+@pytest.fixture()
+def jit_api(hip):
+    """every API kernel of a board without a built-in variant is compiled at its first launch"""
+    saved = {k: os.environ.get(k) for k in ("MNK_JIT_API", "MNK_JIT")}
+    os.environ["MNK_JIT_API"] = "1"
+    hip.lib.reload_config()
+    yield hip.lib
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    hip.lib.reload_config()
+
+
+# (m, n, k): words per plane 5, 2, 1, 5, 1, 11 (rows of 33 cells: no packed write-out), 3, 21 (625 cells)
+SHAPES = [(12, 12, 5), (6, 7, 4), (5, 5, 4), (11, 11, 5), (4, 6, 3), (10, 33, 5), (7, 9, 7), (25, 25, 5)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_fuzzers_on_the_specialised_api_kernels(hip, jit_api, shape, monkeypatch):
+    """every env operation, the wrapper (scripted opponents: pre + post; a third of its steps through the folded draw),
+    the one-launch step: == the oracle after every operation, with the board's own kernels from the first launch on"""
+    lib = jit_api
+    monkeypatch.setattr(fz, "_shape", lambda rng: shape)
+    fz._MAX_WRAPPER_STEPS[0] = 120
+    try:
+        base = 700 + 10 * SHAPES.index(shape)
+        fz.test_env_fuzz(hip, base)
+        fz.test_env_fuzz(hip, base + 1)
+        fz.test_wrapper_fuzz(hip, base)       # LowestLegal opponent, f32 observations
+        fz.test_wrapper_fuzz(hip, base + 1)   # HighestLegal, bf16
+        fz.test_rollout_and_log_fuzz(hip, base)  # (its one-launch plies: mnk_step_random)
+    finally:
+        fz._MAX_WRAPPER_STEPS[0] = 10 ** 9
+    m, n, k = shape
+    for kind in (lib.JIT_API_STEP, lib.JIT_API_STEP_DRAW, lib.JIT_API_STEP_SUBSET, lib.JIT_API_OBSERVE, lib.JIT_API_SP_PRE,
+                 lib.JIT_API_SP_POST):
+        if kind == lib.JIT_API_OBSERVE and shape == (7, 9, 7):
+            continue  # a kernel that never looks at k: this board shares the built-in 9-wide, 3-word variant (9x9x5's)
+        assert lib.jit_api_ready(m, n, k, kind), (shape, kind, lib.load().mnk_jit_last_error())
+    assert not lib.jit_api_ready(9, 9, 5, lib.JIT_API_STEP)  # a board with a built-in variant never gets one
+
+
+@pytest.mark.parametrize("opponent", ["random", "scripted", "net"])
+@pytest.mark.parametrize("m,n,k,nenv", [(12, 12, 5, 300), (6, 7, 4, 257), (5, 5, 4, 130), (10, 33, 5, 70), (11, 11, 5, 65536)])
+def test_folded_draw_of_any_row_width(hip, jit_api, m, n, k, nenv, opponent):
+    """``wrapper.step_logits`` on a board without a compile-time draw shape used to be two launches inside the call; its
+    specialised kernels draw inside the step (mnk_draw::Shape by row width: the sampler's own shape, so the same action
+    for the same uniform): == ``sampler.draw`` + ``wrapper.step``, f32 / bf16 / absent logits, stochastic and
+    deterministic, every output and the whole state"""
+    lib = jit_api
+    from alg.rollout_buffer import RolloutBuffer
+    from selfplay import graphed, policy
+
+    class NS:  # the namespace the fused-draw tests take from their own fixture
+        pass
+
+    ns = NS()
+    ns.lib, ns.Env, ns.Wrapper, ns.policy, ns.graphed, ns.Buffer = lib, hip.Env, hip.Wrapper, policy, graphed, RolloutBuffer
+    fd.test_step_logits_equals_sample_then_step(ns, m, n, k, nenv, opponent)
+    which = 2 if opponent == "random" else 0
+    for dtype in (torch.float32, torch.bfloat16, None):
+        assert lib.jit_api_ready(m, n, k, lib.jit_api_draw_kind(which, dtype)), (m, n, k, dtype)
+    if opponent == "net":
+        assert lib.jit_api_ready(m, n, k, lib.jit_api_draw_kind(1, torch.float32))  # the opponent's draw inside `post`
+
+
+def _play(wrap, ora, steps, rng, where):
+    """`steps` agent-steps of random legal moves on the HIP wrapper and on the oracle, compared after every step"""
+    o1, _ = wrap.reset()
+    o2, _ = ora.reset()
+    for t in range(steps):
+        mask = o2["action_mask"].numpy()
+        acts = torch.from_numpy(np.array([rng.choice(np.nonzero(row)[0]) for row in mask]))
+        o1, r1, t1, _, _ = wrap.step(acts.to(DEV))
+        o2, r2, t2, _, _ = ora.step(acts)
+        assert torch.equal(o1["observation"].cpu(), o2["observation"]), f"{where} step {t}"
+        assert torch.equal(o1["action_mask"].cpu(), o2["action_mask"]), f"{where} step {t}"
+        assert torch.equal(r1.cpu(), r2) and torch.equal(t1.cpu(), t2), f"{where} step {t}"
+
+
+def test_a_kernel_switches_to_its_own_variant_once_it_is_hot(hip):
+    """Default policy (no MNK_JIT_API): the generic kernels run until a kernel has been launched 128 times on the board
+    (or has covered 2^22 items), then the board's own variant takes over -- in the middle of a game, with the same
+    results (the oracle checks every step on both sides of the switch)."""
+    lib = hip.lib
+    for key in ("MNK_JIT_API", "MNK_JIT"):
+        assert os.environ.get(key) is None, "this test needs the default policy"
+    lib.reload_config()
+    m, n, k, nenv = 8, 10, 4, 96  # a board no other test uses: its counters start at zero in this process
+    wrap = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV), seed=3)
+    sides = torch.zeros(nenv, dtype=torch.long)
+    wrap.force_sides(sides)
+    wrap.set_opponent(LowestLegalPolicy())
+    ora = fz._ForcedSides(OracleVectorEnv(m, n, k, nenv))
+    ora.sides = sides
+    ora.set_opponent(LowestLegalPolicy())
+    rng = np.random.default_rng(5)
+    _play(wrap, ora, 100, rng, "before the switch")  # reset = launch 1 of pre / post, then 100 steps
+    assert not lib.jit_api_ready(m, n, k, lib.JIT_API_SP_PRE) and not lib.jit_api_ready(m, n, k, lib.JIT_API_SP_POST)
+    _play(wrap, ora, 60, rng, "across the switch")
+    assert lib.jit_api_ready(m, n, k, lib.JIT_API_SP_PRE) and lib.jit_api_ready(m, n, k, lib.JIT_API_SP_POST)
+    # 2^22 items: one launch over 2^22 envs would do it; 8 launches over 2^19 envs do
+    big = hip.Env(5, 6, 4, 1 << 19, device=DEV)
+    acts = torch.zeros(1 << 19, dtype=torch.long, device=DEV)
+    for t in range(7):
+        big.step(acts + t)
+    assert not lib.jit_api_ready(5, 6, 4, lib.JIT_API_STEP)
+    for t in range(7, 9):
+        big.step(acts + t)
+    assert lib.jit_api_ready(5, 6, 4, lib.JIT_API_STEP)
+    big.check_errors()
+
+
+def test_nothing_is_compiled_under_a_capture_and_prepare_comes_before_it(hip, jit_api):
+    """A launch whose stream is being captured into a hipGraph never compiles or loads a code object (either would
+    invalidate the capture): it takes the generic kernel, and the graph replays to the same results.  ``jit_prepare``
+    before the capture puts the board's own kernels into the graph."""
+    lib = jit_api
+    m, n, k, nenv = 7, 8, 4, 200
+    c = m * n
+
+    def rollout(prepare):
+        env = hip.Env(m, n, k, nenv, device=DEV)
+        wrap = hip.Wrapper(env, seed=11)
+        from selfplay.policy import RandomPolicy
+
+        wrap.set_opponent(RandomPolicy(c, seed=2))
+        if prepare:
+            assert lib.jit_prepare(m, n, k, [lib.JIT_API_SP_STEP, lib.JIT_API_SAMPLE_LEGAL]) == 2
+        out = {"observation": torch.empty((nenv, 2, m, n), dtype=torch.float32, device=DEV),
+               "action_mask": torch.empty((nenv, c), dtype=torch.bool, device=DEV),
+               "rewards": torch.empty(nenv, dtype=torch.float32, device=DEV),
+               "terminated": torch.empty(nenv, dtype=torch.bool, device=DEV)}
+        acts = torch.empty(nenv, dtype=torch.long, device=DEV)
+        step_dev = torch.zeros(1, dtype=torch.int64, device=DEV)
+        side = torch.cuda.Stream(DEV)
+        side.wait_stream(torch.cuda.current_stream(DEV))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            wrap.reset(out=out)  # eager: not captured (step 0 of the wrapper's Philox stream)
+        torch.cuda.current_stream(DEV).wait_stream(side)
+        wrap.step_dev = step_dev  # from here on the step counter advances in device memory
+        with torch.cuda.graph(graph):
+            env.sample_legal_into(acts, seed=9, step=0, step_dev=step_dev)
+            wrap._advance(acts, None, out=out)
+            step_dev.add_(1)
+        trace = []
+        for _ in range(40):
+            graph.replay()
+            trace.append((out["observation"].clone(), out["action_mask"].clone(), out["rewards"].clone(),
+                          out["terminated"].clone(), acts.clone()))
+        env.check_errors()
+        return trace
+
+    ready = lambda kind: lib.jit_api_ready(m, n, k, kind)
+    os.environ.pop("MNK_JIT_API")
+    lib.reload_config()
+    generic = rollout(prepare=False)  # the default policy, 41 launches: nothing is hot, everything generic
+    assert not ready(lib.JIT_API_SP_STEP) and not ready(lib.JIT_API_SAMPLE_LEGAL)
+    os.environ["MNK_JIT_API"] = "1"
+    lib.reload_config()
+    mixed = rollout(prepare=False)
+    # the eager reset compiled the step kernel at its first launch; the draw's first launch was under the capture
+    assert ready(lib.JIT_API_SP_STEP) and not ready(lib.JIT_API_SAMPLE_LEGAL), "a capture must not compile"
+    special = rollout(prepare=True)
+    assert ready(lib.JIT_API_SP_STEP) and ready(lib.JIT_API_SAMPLE_LEGAL)
+    for t, (a, b, c3) in enumerate(zip(generic, mixed, special)):
+        assert all(torch.equal(x, y) for x, y in zip(a, b)), f"replay {t} (generic / mixed)"
+        assert all(torch.equal(x, y) for x, y in zip(a, c3)), f"replay {t} (generic / specialised)"
+    assert any(bool(a[3].any()) for a in generic), "no game ended: the comparison saw no reset"
+    assert lib.jit_prepare(9, 9, 5, [lib.JIT_API_SP_STEP]) == 0  # a built-in board: nothing to prepare
+
+
+@pytest.mark.parametrize("agent,opponent,packed", [("net", "nn", False), ("net", "random", True), ("random", "random", False)])
+def test_a_captured_rollout_runs_the_boards_own_kernels(hip, agent, opponent, packed):
+    """``GraphedRollout`` on a board without a built-in variant, under the DEFAULT policy (nothing forced): its warm-up
+    rollout launches every kernel a handful of times -- far from hot -- and a capture cannot compile, so the constructor
+    prepares the kernels the warm-up touched (``jit_prepare``) before it captures.  The graph then replays the
+    specialised kernels, and fills the buffer like the eager loop, rollout after rollout."""
+    lib = hip.lib
+    for key in ("MNK_JIT_API", "MNK_JIT"):
+        assert os.environ.get(key) is None, "this test needs the default policy"
+    lib.reload_config()
+    from alg.packed_rollout_buffer import PackedRolloutBuffer
+    from alg.rollout_buffer import RolloutBuffer
+    from selfplay import policy
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.lib, ns.Env, ns.Wrapper, ns.Buffer, ns.PackedBuffer, ns.policy = lib, hip.Env, hip.Wrapper, RolloutBuffer, PackedRolloutBuffer, policy
+    board = {"nn": (6, 8, 4), "random": (7, 6, 4)}[opponent] if not packed else (8, 7, 5)  # boards no other test touches
+    sk.graphed_rollout_against_the_eager_loop(ns, agent, opponent, packed, board)
+    m, n, k = board
+    logits = torch.float32 if agent == "net" else None
+    if opponent == "random":
+        assert lib.jit_api_ready(m, n, k, lib.jit_api_draw_kind(2, logits))   # the whole step, the agent's draw folded in
+    else:
+        assert lib.jit_api_ready(m, n, k, lib.jit_api_draw_kind(0, logits))   # pre with the agent's draw
+        assert lib.jit_api_ready(m, n, k, lib.jit_api_draw_kind(1, torch.float32))  # post with the opponent's
+
+
+def test_records_and_minibatches_through_the_specialised_write_outs(hip, jit_api):
+    """``mnk_unpack_records`` (records -> RolloutBuffer layout) and ``mnk_gather_obs`` (minibatch from packed planes) of
+    a board without a built-in variant, specialised: == the generic kernels' output (MNK_JIT_API=0), which the records
+    and the observations they are compared with elsewhere pin to the oracle; bf16 through the packed write-out too"""
+    lib = jit_api
+    from alg.packed_rollout_buffer import PackedRolloutBuffer
+
+    m, n, k, nenv, t = 12, 12, 5, 333, 12
+
+    def run():
+        env = hip.Env(m, n, k, nenv, device=DEV)
+        roll = hip.rollout.RandomRollout(env, seed=31)
+        roll.run(30, record=False)
+        rec = roll.run(t)
+        fields = hip.rollout.unpack_records(rec, env)
+        narrow = hip.rollout.unpack_records(rec, env, obs_dtype=torch.bfloat16)["observations"]
+        # the same observations as packed planes (what a PackedRolloutBuffer stores), through the env's own packer
+        buf = PackedRolloutBuffer(t, nenv, m, n, device=DEV)
+        obs = fields["observations"]  # [t, N, 2, m, n] f32
+        scratch = hip.Env(m, n, k, nenv, device=DEV)
+        for j in range(t):
+            scratch.boards = obs[j]
+            buf.planes[j].copy_(scratch._planes)
+        g = torch.Generator(device="cpu").manual_seed(1)
+        idx = torch.randperm(t * nenv, generator=g)[:500].to(DEV)
+        o, mk = buf.gather(idx)
+        flat_obs = obs.reshape(t * nenv, 2, m, n)
+        assert torch.equal(o, flat_obs[idx])  # (fix_empty only touches full boards: none after 42 plies of 144 cells)
+        assert torch.equal(mk, fields["action_masks"].reshape(t * nenv, -1)[idx])
+        return [fields[key].clone() for key in sorted(fields)] + [narrow.clone(), o.clone(), mk.clone()]
+
+    os.environ["MNK_JIT_API"] = "0"
+    lib.reload_config()
+    want = run()
+    os.environ["MNK_JIT_API"] = "1"
+    lib.reload_config()
+    got = run()
+    assert lib.jit_api_ready(m, n, k, lib.JIT_API_GATHER_OBS) and lib.jit_api_ready(m, n, k, lib.JIT_API_UNPACK_RECORDS)
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)

@@ -362,13 +362,19 @@ def test_graphed_rollout_fills_the_buffer_like_the_eager_loop(hip, agent, oppone
     """selfplay/graphed.py GraphedRollout: n_steps agent-steps as one captured graph writing into the buffer's rows ==
     the eager PPO loop (net -> fused draw -> wrapper.step -> buffer.add) with the same seeds, rollout after rollout
     (the observation carried over between rollouts included)."""
+    graphed_rollout_against_the_eager_loop(hip, agent, opponent, packed, (3, 3, 3))
+
+
+def graphed_rollout_against_the_eager_loop(hip, agent, opponent, packed, board):
+    """(tests/test_gpu_jit_api.py runs the same comparison on boards whose kernels are compiled at run time)"""
     import copy
 
     import torch.nn as nn
 
     from selfplay.graphed import GraphedRollout
 
-    m, n, k, nenv, c, steps, rollouts = 3, 3, 3, 200, 9, 7, 3  # an odd number of steps: the scratch slots swap roles
+    m, n, k = board
+    nenv, c, steps, rollouts = 200, m * n, 7, 3  # an odd number of steps: the scratch slots swap roles
 
     class Net(nn.Module):
         def __init__(self):
