@@ -30,8 +30,8 @@ for (m, n, k, N) in ((9, 9, 5, 65536), (19, 19, 5, 32768)):
     def fused():
         mnk_hip.call("mnk_selfplay_step_random", mnk_hip.ptr(env._planes), mnk_hip.ptr(env._meta), N, m, n, k,
                      mnk_hip.ptr(acts), mnk_hip.ptr(wrap.pending_resets), mnk_hip.ptr(wrap.agent_side), None, 1, 5, None, 0,
-                     mnk_hip.ptr(rew), mnk_hip.ptr(term), mnk_hip.ptr(obs), mnk_hip.ptr(mask), mnk_hip.ptr(env._err),
-                     None, None, None, env._stream())
+                     mnk_hip.ptr(rew), mnk_hip.ptr(term), mnk_hip.ptr(obs), mnk_hip.OBS_F32, mnk_hip.ptr(mask), None,
+                     mnk_hip.ptr(env._err), None, None, None, 0, env._stream())
     t_f = timeit(fused)
     print(f"  {m}x{n} N={N}: observe {t_obs:6.1f} us   fused step {t_f:6.1f} us", flush=True)
 ''' % ROOT

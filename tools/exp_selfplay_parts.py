@@ -48,7 +48,8 @@ def main(m, n, k, N):
 
     def step(o, mk):
         mnk_hip.call("mnk_selfplay_step_random", p(env._planes), p(env._meta), N, m, n, k, p(acts), p(pend), p(side_t),
-                     None, 5, 7, None, 0, p(rew), p(term), p(o), p(mk), p(env._err), None, None, None, 0, env._stream())
+                     None, 5, 7, None, 0, p(rew), p(term), p(o), mnk_hip.OBS_F32, p(mk), None, p(env._err), None, None, None,
+                     0, env._stream())
 
     full = graph_time(lambda: step(obs, mask))
     logic = graph_time(lambda: step(None, None))
