@@ -342,6 +342,11 @@ int64_t mnk_jit_compile_api(int m, int n, int k, int kind);
  * launched on this board so far -- after a warm-up run, exactly what a capture is going to launch): the number ready, 0
  * for a board with a built-in variant or with MNK_JIT_API / MNK_JIT = 0, or a negative status */
 int mnk_jit_prepare(int m, int n, int k, int64_t kinds);
+/* Compiled code objects are kept on disk and reused by later processes: directory $MNK_JIT_CACHE (default
+ * $XDG_CACHE_HOME/mnk_hip or ~/.cache/mnk_hip; "0" or "off": no cache), one file per (this build's embedded sources, hiprtc
+ * version, options, kernel), checksummed, written by rename.  mnk_jit_stats: out4 = {programs compiled by hiprtc, code
+ * objects read from the cache instead, written to it, failed compilations} of this process. */
+int mnk_jit_stats(int64_t* out4);
 /* 1 when the board's own variant of `kind` is loaded on the current device (what the next launch will run), else 0 */
 int mnk_jit_api_ready(int m, int n, int k, int kind);
 

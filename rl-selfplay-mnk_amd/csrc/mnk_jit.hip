@@ -8,8 +8,12 @@
 // built-in boards, embedded in this library at build time -- with the board's NW / n / k as template arguments, and
 // every later launch runs that code object.  One compile per (board, record?, log width) and process, a few seconds.
 // The reference (env/torch_vector_mnk_env.py:7-32) takes any m, n, k; this keeps every board on the fast path.
+#include <errno.h>
 #include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -33,6 +37,118 @@ std::mutex g_mu;
 std::map<std::tuple<int, int, int, int, int, int, int, int>, Compiled> g_cache;
 thread_local char g_jit_err[2048] = "";
 
+// ---- code objects on disk -------------------------------------------------------------------------------------------
+// A board's first hot kernel waits 0.3-1.6 s for hiprtc, in every process.  Compiled code objects are therefore kept in
+// $MNK_JIT_CACHE (default $XDG_CACHE_HOME/mnk_hip or ~/.cache/mnk_hip; "0" / "off" / no home directory: no cache), one
+// file per (embedded sources, hiprtc version, program, options, kernel name), named by the FNV-1a hash of all of those:
+// another build of the library or another ROCm never reads this build's files.  A file that is short, carries another key
+// or fails its checksum is ignored and rewritten; files appear by rename, so a reader never sees half of one.
+std::atomic<int64_t> g_stat_compiled{0}, g_stat_hits{0}, g_stat_stores{0}, g_stat_failed{0};
+
+uint64_t fnv1a(uint64_t h, const void* p, size_t n) {
+  const unsigned char* b = (const unsigned char*)p;
+  for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001B3ull; }
+  return h;
+}
+uint64_t fnv1a(uint64_t h, const std::string& s) { return fnv1a(fnv1a(h, s.data(), s.size()), "\0", 1); }
+
+uint64_t sources_hash() {
+  static const uint64_t h = [] {
+    uint64_t x = 0xCBF29CE484222325ull;
+    int major = 0, minor = 0;
+    hiprtcVersion(&major, &minor);
+    const int v[3] = {MNK_ABI_VERSION, major, minor};
+    x = fnv1a(x, v, sizeof(v));
+    for (int i = 0; i < MNK_JIT_HEADER_COUNT; ++i) {
+      x = fnv1a(x, std::string(mnk_jit_header_names[i]));
+      x = fnv1a(x, std::string(mnk_jit_header_texts[i]));
+    }
+    return x;
+  }();
+  return h;
+}
+
+std::string cache_dir() {
+  if (const char* v = getenv("MNK_JIT_CACHE")) {
+    if (!*v || !strcmp(v, "0") || !strcmp(v, "off")) return "";
+    return v;
+  }
+  if (const char* x = getenv("XDG_CACHE_HOME")) if (*x) return std::string(x) + "/mnk_hip";
+  if (const char* h = getenv("HOME")) if (*h) return std::string(h) + "/.cache/mnk_hip";
+  return "";
+}
+
+bool make_dirs(const std::string& dir) {
+  for (size_t i = 1; i <= dir.size(); ++i)
+    if (i == dir.size() || dir[i] == '/') {
+      const std::string part = dir.substr(0, i);
+      if (mkdir(part.c_str(), 0700) != 0 && errno != EEXIST) return false;
+    }
+  return true;
+}
+
+struct CacheHeader {
+  char magic[8];  // "MNKJIT1"
+  uint64_t key, check;
+  uint32_t name_len, reserved;
+  uint64_t code_len;
+};
+
+std::string cache_path(const std::string& dir, uint64_t key) {
+  char name[40];
+  snprintf(name, sizeof(name), "/%016llx.co", (unsigned long long)key);
+  return dir + name;
+}
+
+bool cache_load(uint64_t key, std::vector<char>& code, std::string& lowered) {
+  const std::string dir = cache_dir();
+  if (dir.empty()) return false;
+  FILE* f = fopen(cache_path(dir, key).c_str(), "rb");
+  if (!f) return false;
+  CacheHeader h;
+  bool ok = fread(&h, sizeof(h), 1, f) == 1 && !memcmp(h.magic, "MNKJIT1", 8) && h.key == key && h.name_len < 4096 &&
+            h.code_len > 0 && h.code_len < (1ull << 30);
+  if (ok) {
+    lowered.assign(h.name_len, '\0');
+    code.resize(h.code_len);
+    ok = (h.name_len == 0 || fread(&lowered[0], h.name_len, 1, f) == 1) && fread(code.data(), h.code_len, 1, f) == 1 &&
+         fgetc(f) == EOF;
+    if (ok) ok = fnv1a(fnv1a(0xCBF29CE484222325ull, lowered.data(), lowered.size()), code.data(), code.size()) == h.check;
+  }
+  fclose(f);
+  if (ok) g_stat_hits++;
+  return ok;
+}
+
+void cache_store(uint64_t key, const std::vector<char>& code, const std::string& lowered) {
+  const std::string dir = cache_dir();
+  if (dir.empty() || code.empty() || !make_dirs(dir)) return;
+  CacheHeader h;
+  memset(&h, 0, sizeof(h));
+  memcpy(h.magic, "MNKJIT1", 8);
+  h.key = key;
+  h.name_len = (uint32_t)lowered.size();
+  h.code_len = code.size();
+  h.check = fnv1a(fnv1a(0xCBF29CE484222325ull, lowered.data(), lowered.size()), code.data(), code.size());
+  const std::string path = cache_path(dir, key);
+  char tmp[64];
+  snprintf(tmp, sizeof(tmp), ".tmp.%ld.%llx", (long)getpid(), (unsigned long long)key);
+  const std::string tpath = dir + "/" + tmp;
+  FILE* f = fopen(tpath.c_str(), "wb");
+  if (!f) return;
+  const bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && (lowered.empty() || fwrite(lowered.data(), lowered.size(), 1, f) == 1) &&
+                  fwrite(code.data(), code.size(), 1, f) == 1;
+  if (fclose(f) != 0 || !ok || rename(tpath.c_str(), path.c_str()) != 0) { unlink(tpath.c_str()); return; }
+  g_stat_stores++;
+}
+
+// key of one compilation: the embedded sources + everything handed to hiprtc for it
+uint64_t compile_key(const char* program, const char* const* opts, int nopts, const std::string& expr) {
+  uint64_t k = fnv1a(sources_hash(), std::string(program));
+  for (int i = 0; i < nopts; ++i) k = fnv1a(k, std::string(opts[i]));
+  return fnv1a(k, expr);
+}
+
 // compiles the rollout (kind 0) or the replay kernel (kind 1) for this geometry; code object bytes in `code` (no GPU
 // needed for this part)
 bool compile(const MnkGeom& g, bool rec, int act, bool saddr, std::vector<char>& code, int kind = 0) {
@@ -50,8 +166,13 @@ bool compile(const MnkGeom& g, bool rec, int act, bool saddr, std::vector<char>&
                     d_kind = "-DMNK_JIT_KIND=" + std::to_string(kind);
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", d_nw.c_str(), d_cn.c_str(),
                         d_ck.c_str(), d_rec.c_str(), d_act.c_str(), d_sa.c_str(), d_kind.c_str()};
-  const hiprtcResult rc = hiprtcCompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+  const int nopts = (int)(sizeof(opts) / sizeof(opts[0]));
+  const uint64_t key = compile_key(program, opts, nopts, "");
+  std::string no_name;
+  if (cache_load(key, code, no_name)) { hiprtcDestroyProgram(&prog); return true; }
+  const hiprtcResult rc = hiprtcCompileProgram(prog, nopts, opts);
   if (rc != HIPRTC_SUCCESS) {
+    g_stat_failed++;
     size_t n = 0;
     hiprtcGetProgramLogSize(prog, &n);
     std::string log(n, '\0');
@@ -65,6 +186,10 @@ bool compile(const MnkGeom& g, bool rec, int act, bool saddr, std::vector<char>&
   code.resize(n);
   hiprtcGetCode(prog, code.data());
   hiprtcDestroyProgram(&prog);
+  if (n > 0) {
+    g_stat_compiled++;
+    cache_store(key, code, no_name);
+  }
   return n > 0;
 }
 
@@ -177,11 +302,15 @@ bool compile_api(const MnkGeom& g, int kind, std::vector<char>& code, std::strin
     return false;
   }
   const std::string expr = "&" + api_kernel_name(g, kind);
-  bool ok = hiprtcAddNameExpression(prog, expr.c_str()) == HIPRTC_SUCCESS;
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+  const int nopts = (int)(sizeof(opts) / sizeof(opts[0]));
+  const uint64_t key = compile_key(program, opts, nopts, expr);
+  if (cache_load(key, code, lowered)) { hiprtcDestroyProgram(&prog); return true; }
+  bool ok = hiprtcAddNameExpression(prog, expr.c_str()) == HIPRTC_SUCCESS;
   hiprtcResult rc = HIPRTC_SUCCESS;
-  if (ok) rc = hiprtcCompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+  if (ok) rc = hiprtcCompileProgram(prog, nopts, opts);
   if (!ok || rc != HIPRTC_SUCCESS) {
+    g_stat_failed++;
     size_t n = 0;
     hiprtcGetProgramLogSize(prog, &n);
     std::string log(n, '\0');
@@ -203,6 +332,10 @@ bool compile_api(const MnkGeom& g, int kind, std::vector<char>& code, std::strin
   code.resize(n);
   hiprtcGetCode(prog, code.data());
   hiprtcDestroyProgram(&prog);
+  if (n > 0) {
+    g_stat_compiled++;
+    cache_store(key, code, lowered);
+  }
   return n > 0;
 }
 
@@ -304,6 +437,14 @@ int mnk_jit_api_ready(int m, int n, int k, int kind) {
   std::lock_guard<std::mutex> lock(g_mu);
   auto it = g_api_cache.find(std::make_tuple(device, g.m, g.n, mnk_jit_kind_any_k(kind) ? 0 : g.k, kind));
   return it != g_api_cache.end() && it->second.c.fn ? 1 : 0;
+}
+
+// what the run-time compiler has done in this process: out[0] programs compiled by hiprtc, out[1] code objects taken from
+// the cache on disk instead ($MNK_JIT_CACHE), out[2] written to it, out[3] failed compilations
+int mnk_jit_stats(int64_t* out4) {
+  if (!out4) return MNK_EINVAL;
+  out4[0] = g_stat_compiled; out4[1] = g_stat_hits; out4[2] = g_stat_stores; out4[3] = g_stat_failed;
+  return MNK_OK;
 }
 
 const char* mnk_jit_last_error(void) { return g_jit_err; }

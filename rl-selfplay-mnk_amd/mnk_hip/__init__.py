@@ -79,6 +79,7 @@ SIGNATURES = {
     "mnk_jit_compile_api": [_i, _i, _i, _i],
     "mnk_jit_prepare": [_i, _i, _i, _i64],
     "mnk_jit_api_ready": [_i, _i, _i, _i],
+    "mnk_jit_stats": [_vp],
     "mnk_comm_unique_id": [_vp],
     "mnk_comm_init": [_vp, _vp, _i, _i],
     "mnk_comm_destroy": [_vp],
@@ -216,6 +217,14 @@ def jit_prepare(m: int, n: int, k: int, kinds=None) -> int:
     if rc < 0:
         raise MnkHipError(f"mnk_jit_prepare({m}, {n}, {k}): {_STATUS.get(rc, rc)}: " + (lib.mnk_jit_last_error() or b"").decode())
     return rc
+
+
+def jit_stats() -> dict:
+    """what the run-time compiler did in this process: programs compiled by hiprtc, code objects read from the cache on
+    disk instead (``$MNK_JIT_CACHE``, default ``~/.cache/mnk_hip``; "0": off), written to it, failed compilations"""
+    out = (ctypes.c_int64 * 4)()
+    load().mnk_jit_stats(out)
+    return dict(zip(("compiled", "cache_hits", "cache_stores", "failed"), (int(v) for v in out)))
 
 
 def jit_api_ready(m: int, n: int, k: int, kind: int) -> bool:

@@ -11,6 +11,10 @@ for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# run-time compiled kernels are not taken from (or left in) the user's cache on disk: the suite is also the check that the
+# embedded sources still compile, and must not depend on what an earlier run left behind
+os.environ.setdefault("MNK_JIT_CACHE", "0")
+
 # the oracle is torch-eager on small batches: a GPU box's 256 logical CPUs make every tiny op slower, not faster
 try:
     import torch

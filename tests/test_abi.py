@@ -126,6 +126,46 @@ def test_api_kernels_specialise_at_run_time_without_a_gpu(lib):
     assert handle.mnk_jit_compile_api(40, 40, 5, 0) == -2                   # beyond the packed layout
 
 
+def test_compiled_code_objects_are_reused_from_disk(lib, tmp_path, monkeypatch):
+    """$MNK_JIT_CACHE: a code object hiprtc produced is written to disk (by rename, checksummed, keyed by the embedded
+    sources + hiprtc version + options + kernel) and the next compilation of the same kernel -- in this or a later
+    process -- reads it back instead of compiling; a damaged file is ignored and replaced; "0" switches the cache off."""
+    import time
+
+    handle = lib.load()
+    cache = tmp_path / "jit"
+    monkeypatch.setenv("MNK_JIT_CACHE", str(cache))
+    s0 = lib.jit_stats()
+    t0 = time.time()
+    size = handle.mnk_jit_compile_api(9, 10, 4, lib.JIT_API_SP_STEP)
+    cold = time.time() - t0
+    assert size > 4096
+    files = sorted(cache.glob("*.co"))
+    s1 = lib.jit_stats()
+    assert len(files) == 1 and s1["compiled"] == s0["compiled"] + 1 and s1["cache_stores"] == s0["cache_stores"] + 1
+    t0 = time.time()
+    assert handle.mnk_jit_compile_api(9, 10, 4, lib.JIT_API_SP_STEP) == size
+    warm = time.time() - t0
+    s2 = lib.jit_stats()
+    assert s2["cache_hits"] == s1["cache_hits"] + 1 and s2["compiled"] == s1["compiled"] and warm < cold / 4, (cold, warm)
+    # the rollout kernel's programs go through the same cache; another kernel = another file
+    assert handle.mnk_jit_compile_rollout(9, 10, 4, 1, 0) > 4096 and handle.mnk_jit_compile_rollout(9, 10, 4, 1, 0) > 4096
+    assert len(list(cache.glob("*.co"))) == 2 and lib.jit_stats()["cache_hits"] == s2["cache_hits"] + 1
+    # a damaged file (truncated; a flipped byte) is not trusted
+    blob = files[0].read_bytes()
+    files[0].write_bytes(blob[: len(blob) // 2])
+    assert handle.mnk_jit_compile_api(9, 10, 4, lib.JIT_API_SP_STEP) == size
+    assert lib.jit_stats()["compiled"] == s2["compiled"] + 2 and files[0].read_bytes() == blob   # (+1: the rollout above)
+    files[0].write_bytes(blob[:-1] + bytes([blob[-1] ^ 1]))
+    assert handle.mnk_jit_compile_api(9, 10, 4, lib.JIT_API_SP_STEP) == size and files[0].read_bytes() == blob
+    assert not list(cache.glob(".tmp*"))
+    monkeypatch.setenv("MNK_JIT_CACHE", "0")
+    before = lib.jit_stats()
+    assert handle.mnk_jit_compile_api(9, 10, 4, lib.JIT_API_SP_STEP) == size
+    after = lib.jit_stats()
+    assert after["compiled"] == before["compiled"] + 1 and after["cache_hits"] == before["cache_hits"]
+
+
 def test_header_is_plain_c(tmp_path):
     """include/mnk_hip.h is a C ABI: it must compile as C99 (a cgo / JNI / plain C host includes it as is) and as C++."""
     import subprocess

@@ -272,3 +272,46 @@ def test_records_and_minibatches_through_the_specialised_write_outs(hip, jit_api
     assert lib.jit_api_ready(m, n, k, lib.JIT_API_GATHER_OBS) and lib.jit_api_ready(m, n, k, lib.JIT_API_UNPACK_RECORDS)
     for a, b in zip(want, got):
         assert torch.equal(a, b)
+
+
+def test_a_later_process_loads_its_kernels_from_the_cache_on_disk(hip, tmp_path):
+    """``$MNK_JIT_CACHE``: the second process to play on a board compiles nothing -- its kernels (rollout and API) come
+    from the code objects the first one left on disk -- and plays the same games."""
+    import json
+    import subprocess
+    import sys
+
+    script = r'''
+import hashlib, json, os, sys
+sys.path[:0] = [os.environ["MNK_ROOT"], os.path.join(os.environ["MNK_ROOT"], "rl-selfplay-mnk_amd")]
+import torch
+import mnk_hip
+from env.torch_vector_mnk_env import TorchVectorMnkEnv
+from selfplay.policy import RandomPolicy
+from selfplay.random_rollout import RandomRollout
+from selfplay.torch_self_play_wrapper import TorchSelfPlayWrapper
+env = TorchVectorMnkEnv(8, 11, 4, 1 << 13, device="cuda:0")
+rec = RandomRollout(env, seed=3).run(128)          # 2^20 env-steps: the rollout kernel is specialised
+wrap = TorchSelfPlayWrapper(env, seed=5)
+wrap.set_opponent(RandomPolicy(88, seed=7))
+obs, _ = wrap.reset()
+h = hashlib.sha256(rec.planes.cpu().numpy().tobytes() + rec.meta.cpu().numpy().tobytes())
+for t in range(6):
+    obs, rew, term, _, _ = wrap.step(torch.full((1 << 13,), t, dtype=torch.long, device="cuda:0"))
+    h.update(obs["observation"].cpu().numpy().tobytes() + rew.cpu().numpy().tobytes() + term.cpu().numpy().tobytes())
+env.check_errors()
+print(json.dumps({"digest": h.hexdigest(), "stats": mnk_hip.jit_stats(),
+                  "ready": mnk_hip.jit_api_ready(8, 11, 4, mnk_hip.JIT_API_SP_STEP)}))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MNK_JIT_CACHE=str(tmp_path / "cache"), MNK_JIT_API="1", MNK_ROOT=root)
+    runs = []
+    for _ in range(2):
+        res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, env=env)
+        assert res.returncode == 0, res.stderr[-2000:]
+        runs.append(json.loads(res.stdout.strip().splitlines()[-1]))
+    first, second = runs
+    assert first["ready"] and second["ready"]
+    assert first["stats"]["compiled"] >= 2 and first["stats"]["cache_stores"] == first["stats"]["compiled"]
+    assert second["stats"]["compiled"] == 0 and second["stats"]["cache_hits"] == first["stats"]["compiled"], second
+    assert first["digest"] == second["digest"]
