@@ -248,6 +248,10 @@ void mnk_launch_rollout_pairw(const MnkGeom& g, uint64_t* planes, uint32_t* meta
                               uint64_t step0, int64_t env_id0, uint64_t* rec_planes, uint32_t* rec_meta, int64_t* stats,
                               void* act_log, int act_bytes, void* stream);
 
+// dynamic LDS a launch may ask for without raising the function's limit (the packed write-out stage of a run-time
+// specialised kernel is larger than the table form's: launches that would not fit stay on the ahead-of-time kernels)
+#define MNK_MAX_DYNAMIC_LDS ((size_t)64 * 1024 - 256)  /* (the kernels also hold a few static words) */
+
 // ------------------------------------------------------------------ run-time specialised API-level kernels (mnk_jit.hip)
 // The kernels of mnk_api_kernels.h / mnk_selfplay_kernels.h, compiled by hiprtc with the board's NW / n / k (and, for the
 // forms with a folded-in draw, its cell count) as template arguments.  Boards with a built-in variant never get here.

@@ -216,8 +216,10 @@ int mnk_observe(const uint64_t* planes, const uint32_t* meta, int64_t N, int m, 
   const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
   const dim3 grid((unsigned)((N + B - 1) / B)), block(mnk_block_threads(obs != nullptr));
   hipStream_t s = (hipStream_t)stream;
-  if (hipFunction_t fn = mnk_jit_api_function(g, MNK_JK_OBSERVE, N, s)) {  // the board's own variant (mnk_jit.hip)
-    mnk_module_launch(&k_observe<2, 0, 0>, fn, grid, block, mnk_stage_bytes(g.NW, g.C, B, g.n, mnk_packed_cells(g.n, g.C)), s,
+  const size_t lds_own = mnk_stage_bytes(g.NW, g.C, B, g.n, mnk_packed_cells(g.n, g.C));
+  hipFunction_t fn = lds_own <= MNK_MAX_DYNAMIC_LDS ? mnk_jit_api_function(g, MNK_JK_OBSERVE, N, s) : nullptr;
+  if (fn) {  // the board's own variant (mnk_jit.hip)
+    mnk_module_launch(&k_observe<2, 0, 0>, fn, grid, block, lds_own, s,
                       g, planes, N, flip_side, obs, obs_dtype, legal_mask, fix_empty_mask, packed_obs, vec_ok, B);
     return mnk_launch_status("observe (run-time specialised)");
   }
@@ -253,9 +255,10 @@ static int mnk_launch_step_full(const MnkGeom& g, uint64_t* planes, uint32_t* me
   const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
   const dim3 grid((unsigned)((N + B - 1) / B)), block(mnk_block_threads(obs != nullptr));
   const MnkDraw none = {0, 0, nullptr, 0, 0, nullptr};
-  if (hipFunction_t fn = mnk_jit_api_function(g, draw ? MNK_JK_STEP_DRAW : MNK_JK_STEP, N, s)) {
-    const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, mnk_packed_cells(g.n, g.C)) : 0;
-    mnk_module_launch(&k_step_full<2, 0, 0, false>, fn, grid, block, lds, s, g, planes, meta, N, actions, draw ? *draw : none,
+  const size_t lds_own = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, mnk_packed_cells(g.n, g.C)) : 0;
+  hipFunction_t fn = lds_own <= MNK_MAX_DYNAMIC_LDS ? mnk_jit_api_function(g, draw ? MNK_JK_STEP_DRAW : MNK_JK_STEP, N, s) : nullptr;
+  if (fn) {
+    mnk_module_launch(&k_step_full<2, 0, 0, false>, fn, grid, block, lds_own, s, g, planes, meta, N, actions, draw ? *draw : none,
                       rewards, dones, legal_mask, obs, obs_dtype, err, flags, vec_ok, B);
     return mnk_launch_status(draw ? "step_random (run-time specialised)" : "step (run-time specialised)");
   }
@@ -402,9 +405,10 @@ int mnk_unpack_records(const uint64_t* rec_planes, const uint32_t* rec_meta, int
   const bool mask_vec = aligned16(masks) && ((N * g.C) % 16 == 0);
   const int vec_ok = (obs_vec ? 1 : 0) | (mask_vec ? 2 : 0);
   const dim3 grid((unsigned)((N + B - 1) / B), (unsigned)T);
-  if (hipFunction_t fn = mnk_jit_api_function(g, MNK_JK_UNPACK_RECORDS, N * (int64_t)T, (hipStream_t)stream)) {
-    const size_t lds = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, mnk_packed_cells(g.n, g.C)) : 0;
-    mnk_module_launch(&k_unpack_records<2, 0, 0>, fn, grid, dim3(mnk_block_threads()), lds, (hipStream_t)stream, g, rec_planes,
+  const size_t lds_own = emit ? mnk_stage_bytes(g.NW, g.C, B, g.n, mnk_packed_cells(g.n, g.C)) : 0;
+  hipFunction_t fn = lds_own <= MNK_MAX_DYNAMIC_LDS ? mnk_jit_api_function(g, MNK_JK_UNPACK_RECORDS, N * (int64_t)T, (hipStream_t)stream) : nullptr;
+  if (fn) {
+    mnk_module_launch(&k_unpack_records<2, 0, 0>, fn, grid, dim3(mnk_block_threads()), lds_own, (hipStream_t)stream, g, rec_planes,
                       rec_meta, N, obs, obs_dtype, masks, actions, rewards, dones, vec_ok, B);
     return mnk_launch_status("unpack_records (run-time specialised)");
   }
@@ -424,9 +428,11 @@ int mnk_gather_obs(const uint64_t* planes, int64_t T, int64_t N, int m, int n, c
   const int E = mnk_block_envs(B);
   const int vec_ok = (aligned16(obs) ? 1 : 0) | (aligned16(legal_mask) ? 2 : 0);
   const dim3 grid((unsigned)((B + E - 1) / E));
-  if (hipFunction_t fn = mnk_jit_api_function(g, MNK_JK_GATHER_OBS, B, (hipStream_t)stream)) {
+  const size_t lds_own = mnk_stage_bytes(g.NW, g.C, E, g.n, mnk_packed_cells(g.n, g.C));
+  hipFunction_t fn = lds_own <= MNK_MAX_DYNAMIC_LDS ? mnk_jit_api_function(g, MNK_JK_GATHER_OBS, B, (hipStream_t)stream) : nullptr;
+  if (fn) {
     mnk_module_launch(&k_gather_obs<2, 0, 0>, fn, grid, dim3(mnk_block_threads()),
-                      mnk_stage_bytes(g.NW, g.C, E, g.n, mnk_packed_cells(g.n, g.C)), (hipStream_t)stream, g, planes, T, N, idx, B,
+                      lds_own, (hipStream_t)stream, g, planes, T, N, idx, B,
                       obs, obs_dtype, legal_mask, fix_empty_mask, err, vec_ok, E);
     return mnk_launch_status("gather_obs (run-time specialised)");
   }

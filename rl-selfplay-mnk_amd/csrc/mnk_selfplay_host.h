@@ -134,8 +134,6 @@ template <int WHICH>
 inline bool mnk_launch_sp_jit(const MnkSpArgs& a, const int64_t* moves, const MnkSample& sa, hipStream_t s) {
   int kind = MNK_JK_SP_PRE + WHICH;
   if (!moves) kind = MNK_JK_SP_DRAW + 3 * (!sa.logits ? 2 : (sa.logits_dtype == MNK_LOGITS_BF16 ? 1 : 0)) + WHICH;
-  hipFunction_t fn = mnk_jit_api_function(a.g, kind, a.N, s);
-  if (!fn) return false;
   const MnkSpLaunch l = mnk_sp_launch_shape(a);
   const int B = l.B, vec_ok = l.vec_ok;
   const size_t stage = l.emit ? mnk_stage_bytes(a.g.NW, a.g.C, B, a.g.n, mnk_packed_cells(a.g.n, a.g.C)) : 0;
@@ -143,12 +141,14 @@ inline bool mnk_launch_sp_jit(const MnkSpArgs& a, const int64_t* moves, const Mn
   int span = 0;
   if (!moves) {  // LDS of the draw behind the stage: as mnk_draw_lds_bytes<Draw<LT, C>>, with the shape of this row width
     const int C = a.g.C;
-    const int lpr = mnk_draw::shape_lpr(C);
-    const int rows = l.NT / lpr;
+    const int rows = l.NT / mnk_draw::shape_lpr(C);
     const int ve = !sa.logits ? 16 : (sa.logits_dtype == MNK_LOGITS_BF16 ? 8 : 4);
     span = (int)mnk_stage_span(stage);
     lds = (size_t)span + (size_t)B * 4 + ((size_t)rows * C + 2 * ve + rows) * sizeof(float);
   }
+  if (lds > MNK_MAX_DYNAMIC_LDS) return false;  // (31x31 with the draw folded in: 92 KB -- its two launches stay)
+  hipFunction_t fn = mnk_jit_api_function(a.g, kind, a.N, s);
+  if (!fn) return false;
   if constexpr (WHICH == MNK_SP_PRE)
     mnk_module_launch(&k_selfplay_pre<2, 0, 0, NoDraw>, fn, l.grid, l.block, lds, s, a.g, a.planes, a.meta, a.N, moves, sa,
                       a.pending, a.agent_side, a.forced_side, a.seed, a.step, a.step_dev, a.env_id0, a.rewards, a.terminated,

@@ -95,6 +95,25 @@ def test_folded_draw_of_any_row_width(hip, jit_api, m, n, k, nenv, opponent):
         assert lib.jit_api_ready(m, n, k, lib.jit_api_draw_kind(1, torch.float32))  # the opponent's draw inside `post`
 
 
+def test_a_launch_that_would_not_fit_the_lds_stays_on_two_launches(hip, jit_api):
+    """31x31: the packed write-out stage (61 KB) and the draw's slab of rows (31 KB) do not fit the 64 KB a launch may ask
+    for together, so ``step_logits`` keeps its two launches there (sampler + the specialised plain kernel) -- decided
+    on the host before anything is compiled, same results"""
+    lib = jit_api
+    from alg.rollout_buffer import RolloutBuffer
+    from selfplay import graphed, policy
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.lib, ns.Env, ns.Wrapper, ns.policy, ns.graphed, ns.Buffer = lib, hip.Env, hip.Wrapper, policy, graphed, RolloutBuffer
+    fd.test_step_logits_equals_sample_then_step(ns, 31, 31, 6, 70, "scripted")
+    assert lib.jit_api_ready(31, 31, 6, lib.JIT_API_SP_PRE) and lib.jit_api_ready(31, 31, 6, lib.JIT_API_SP_POST)
+    for dtype in (torch.float32, torch.bfloat16, None):
+        assert not lib.jit_api_ready(31, 31, 6, lib.jit_api_draw_kind(0, dtype))
+
+
 def _play(wrap, ora, steps, rng, where):
     """`steps` agent-steps of random legal moves on the HIP wrapper and on the oracle, compared after every step"""
     o1, _ = wrap.reset()
