@@ -107,5 +107,48 @@ def main():
             print(f"{m}x{n}x{k} N={N} (built-in variant): " + ", ".join(f"{key} {v:.2f}" for key, v in ref.items()), flush=True)
 
 
+def profile(m, n, k, N, launches=200):
+    """for rocprofv3 (tools/profile_script.sh): the same launches on the generic and on the specialised kernels, eager, so
+    that the trace holds both kernel names side by side with their FETCH_SIZE / WRITE_SIZE"""
+    mnk_hip.load()
+    c = m * n
+    for mode in ("0", "1"):
+        os.environ["MNK_JIT_API"] = mode
+        mnk_hip.reload_config()
+        env = TorchVectorMnkEnv(m, n, k, N, device=DEV)
+        RandomRollout(env, seed=0).run(min(150, c), record=False)
+        out = {"observation": torch.empty((N, 2, m, n), dtype=torch.float32, device=DEV),
+               "action_mask": torch.empty((N, c), dtype=torch.bool, device=DEV),
+               "rewards": torch.empty(N, dtype=torch.float32, device=DEV),
+               "terminated": torch.empty(N, dtype=torch.bool, device=DEV)}
+        acts = torch.zeros(N, dtype=torch.long, device=DEV)
+        env.sample_legal_into(acts, seed=1, step=0)
+        logits = torch.randn(N, c, device=DEV)
+        mask = torch.ones((N, c), dtype=torch.bool, device=DEV)
+        sampler = HipSampler(seed=3)
+        a_out = torch.empty(N, dtype=torch.long, device=DEV)
+        lp_out = torch.empty(N, dtype=torch.float32, device=DEV)
+        w = TorchSelfPlayWrapper(env, seed=1)
+        w.set_opponent(RandomPolicy(c, seed=2))
+        w.reset()
+        w2 = TorchSelfPlayWrapper(env, seed=1)
+        w2.set_opponent(Fixed(acts))
+        w2.reset()
+        for _ in range(launches):
+            w._advance(acts, None, out=out)
+            w.step_logits(logits, mask, sampler, out=out, actions_out=a_out, logp_out=lp_out)
+            w2._advance(acts, None, out=out)
+            env.step_into(acts, out["rewards"], out["terminated"], out["action_mask"], out["observation"])
+            env.step_random_into(out["rewards"], out["terminated"], out["action_mask"], seed=5, step=0)
+            env.observe_into(out["observation"], out["action_mask"])
+        torch.cuda.synchronize()
+    print(f"{m}x{n}x{k} x {N} envs: {launches} launches of each call, first on the generic kernels (NW rounded up, CN = CK = 0), "
+          f"then on the board's own (<{(m * (n + 1) + 31) // 32}, {n}, {k}>); algorithmic bytes per self-play step "
+          f"(state both ways + f32 observation + mask + scalars): {N * (2 * (16 * env.words + 8) + 9 * c + 8 + 4 + 1 + 2 + 16) / 1e6:.1f} MB")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "profile":
+        profile(*(int(v) for v in sys.argv[2:6]))
+    else:
+        main()
