@@ -260,7 +260,8 @@ int mnk_selfplay_step_random(uint64_t* planes, uint32_t* meta, int64_t N, int m,
  * `actions` (required) / `logp` (optional) receive the drawn moves and their log-probabilities for ALL N rows (rows whose
  * move is not played -- pending resets, no reply needed -- still draw: the rollout buffer stores them, alg/ppo.py:104).
  * Bit-identical to mnk_sample_logits followed by the plain form.  One launch on 3x3x3, 9x9x5, 13x13x5, 15x15x5 and 19x19x5;
- * other boards take the two launches inside the call.  A network-vs-network agent-step is 2 env-side launches (was 4). */
+ * other boards take the two launches inside the call until the kernel is hot, then one launch of the board's own run-time
+ * compiled variant (ABI 6, below).  A network-vs-network agent-step is 2 env-side launches (was 4). */
 int mnk_selfplay_pre_logits(uint64_t* planes, uint32_t* meta, int64_t N, int m, int n, int k, const void* logits,
                             int logits_dtype, const uint8_t* mask, uint64_t sample_seed, const uint64_t* sample_seed_dev,
                             uint64_t sample_step, const uint64_t* sample_step_dev, int64_t sample_env_id0, int deterministic,

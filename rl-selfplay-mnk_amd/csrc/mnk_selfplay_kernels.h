@@ -14,8 +14,10 @@
 //                    envs is contiguous), leave the chosen cells in LDS (and in `actions` / `logp` in HBM: the rollout
 //                    buffer wants them), then the first B lanes play them.  Same (LPR, K) shape as k_sample_logits, same
 //                    Philox stream: the action of a row is bit-identical to mnk_sample_logits followed by the NoDraw form.
-// Instantiations of the Draw forms live in mnk_selfplay_draw.hip (boards 3x3, 9x9, 13x13, 15x15, 19x19 x f32 / bf16 / no
-// logits); other boards take two launches behind the same C-ABI entry points.
+// Ahead-of-time instantiations of the Draw forms live in mnk_selfplay_{pre,post,step}_logits.hip (boards 3x3, 9x9, 13x13,
+// 15x15, 19x19 x f32 / bf16 / no logits); other boards take two launches behind the same C-ABI entry points until
+// mnk_jit.hip has compiled this header for them (any row width: mnk_draw::Shape).
+// Device code only -- no host includes: hiprtc compiles this text at run time (launchers: mnk_selfplay_host.h).
 #pragma once
 #include "mnk_api_kernels.h"
 #include "mnk_draw.h"

@@ -79,7 +79,8 @@ def _same_state(a, b):
 
 
 BOARDS = [(3, 3, 3, 300), (9, 9, 5, 257), (9, 9, 5, 65536), (13, 13, 5, 130), (15, 15, 5, 70), (19, 19, 5, 300),
-          (7, 9, 4, 100), (9, 9, 4, 64)]  # the last two have no compile-time draw shape: two launches inside the call
+          (7, 9, 4, 100), (9, 9, 4, 64)]  # the last two have no built-in draw shape: two launches inside the call (the fold
+# comes from hiprtc once the kernel is hot: tests/test_gpu_jit_api.py)
 
 
 @pytest.mark.parametrize("opponent", ["random", "scripted", "net"])
