@@ -17,6 +17,7 @@ import torch
 
 import test_gpu_fused_draw as fd
 import test_gpu_fuzz as fz
+import test_gpu_selfplay as sp
 import test_gpu_sink as sk
 from oracle.env_torch import OracleVectorEnv
 from oracle.policies import LowestLegalPolicy
@@ -249,6 +250,33 @@ def test_a_captured_rollout_runs_the_boards_own_kernels(hip, agent, opponent, pa
     else:
         assert lib.jit_api_ready(m, n, k, lib.jit_api_draw_kind(0, logits))   # pre with the agent's draw
         assert lib.jit_api_ready(m, n, k, lib.jit_api_draw_kind(1, torch.float32))  # post with the opponent's
+
+
+@pytest.mark.parametrize("opponent", ["random", "nn"])
+def test_a_captured_agent_step_runs_the_boards_own_kernels(hip, opponent):
+    """the same for ``GraphedAgentStep`` (one agent-step per graph): prepared between its four warm-up steps and the
+    capture, equal to the eager sequence (its twin wrapper comes later and finds the kernels prepared; the captured
+    rollout test above compares specialised replays with a generic eager loop)"""
+    lib = hip.lib
+    for key in ("MNK_JIT_API", "MNK_JIT"):
+        assert os.environ.get(key) is None, "this test needs the default policy"
+    lib.reload_config()
+    from selfplay import policy
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.lib, ns.Env, ns.Wrapper, ns.policy = lib, hip.Env, hip.Wrapper, policy
+    board = (5, 8, 4) if opponent == "random" else (8, 5, 3)   # boards no other test touches
+    sp.graphed_agent_step_against_eager(ns, opponent, board)
+    m, n, k = board
+    if opponent == "random":
+        assert lib.jit_api_ready(m, n, k, lib.jit_api_draw_kind(2, torch.float32))
+        assert lib.jit_api_ready(m, n, k, lib.JIT_API_SP_STEP)   # (the reset before the capture launched the plain form)
+    else:
+        assert lib.jit_api_ready(m, n, k, lib.jit_api_draw_kind(0, torch.float32))
+        assert lib.jit_api_ready(m, n, k, lib.jit_api_draw_kind(1, torch.float32))
 
 
 def test_records_and_minibatches_through_the_specialised_write_outs(hip, jit_api):

@@ -834,13 +834,19 @@ def test_reference_network_end_to_end(hip, golden_dir):
 def test_graphed_agent_step_equals_eager(hip, opponent):
     """selfplay/graphed.py: the captured hipGraph of (net -> fused draw -> wrapper.step) replays to exactly
     what the same sequence does eagerly, step after step (the Philox step counter advances on the device)."""
+    graphed_agent_step_against_eager(hip, opponent, (3, 3, 3))
+
+
+def graphed_agent_step_against_eager(hip, opponent, board):
+    """(tests/test_gpu_jit_api.py runs the same comparison on a board whose kernels are compiled at run time)"""
     import copy
 
     import torch.nn as nn
 
     from selfplay.graphed import GraphedAgentStep
 
-    m, n, k, nenv, c = 3, 3, 3, 384, 9
+    m, n, k = board
+    nenv, c = 384, m * n
 
     class Net(nn.Module):
         def __init__(self):
