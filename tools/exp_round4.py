@@ -1,5 +1,5 @@
 """Developer tool (GPU box): the round-4 measurements that are not part of bench.py.  Run bare for timings, or under
-rocprofv3 (tools/profile_round4.sh) and condense with tools/summarize_trace.py.
+rocprofv3 (tools/profile_script.sh <tag> tools/exp_round4.py <mode>) and condense with tools/summarize_trace.py.
 
     python tools/exp_round4.py fused [m n k envs]     the step kernels with the masked draw folded in against the two
                                                       launches they replace (mnk_sample_logits + plain kernel), 50 launches
