@@ -151,14 +151,14 @@ def test_a_kernel_switches_to_its_own_variant_once_it_is_hot(hip):
     _play(wrap, ora, 60, rng, "across the switch")
     assert lib.jit_api_ready(m, n, k, lib.JIT_API_SP_PRE) and lib.jit_api_ready(m, n, k, lib.JIT_API_SP_POST)
     # 2^22 items: one launch over 2^22 envs would do it; 8 launches over 2^19 envs do
-    big = hip.Env(5, 6, 4, 1 << 19, device=DEV)
+    big = hip.Env(6, 5, 4, 1 << 19, device=DEV)
     acts = torch.zeros(1 << 19, dtype=torch.long, device=DEV)
     for t in range(7):
         big.step(acts + t)
-    assert not lib.jit_api_ready(5, 6, 4, lib.JIT_API_STEP)
+    assert not lib.jit_api_ready(6, 5, 4, lib.JIT_API_STEP)
     for t in range(7, 9):
         big.step(acts + t)
-    assert lib.jit_api_ready(5, 6, 4, lib.JIT_API_STEP)
+    assert lib.jit_api_ready(6, 5, 4, lib.JIT_API_STEP)
     big.check_errors()
 
 
