@@ -320,7 +320,7 @@ const char* mnk_jit_last_error(void);
  * mnk_step / mnk_step_random / mnk_observe / mnk_sample_legal / mnk_unpack_records / mnk_gather_obs / mnk_selfplay_* start
  * on generic code (run-time shift amounts, table write-out) and switch to the board's own variant -- compile-time
  * geometry, the packed write-out, and for mnk_selfplay_*_logits the draw folded into the step kernel for any row width --
- * once they are hot: 128 launches or 2^22 items of that kernel on that board in this process (about a second of hiprtc per
+ * once they are hot: 1 024 launches or 2^26 items of that kernel on that board in this process (about a second of hiprtc per
  * kernel, then a code object load).  MNK_JIT_API=1 (or MNK_JIT=1): at the first launch; =0: never.  Results are identical
  * either way.  Nothing is compiled while the launch's stream is being captured into a hipGraph: call mnk_jit_prepare
  * before the capture.  `kind` / the bits of `kinds`: */

@@ -272,9 +272,11 @@ enum MnkJitApiKind {  // (the public names: MNK_JIT_API_* of include/mnk_hip.h)
 inline bool mnk_jit_kind_any_k(int kind) { return kind >= MNK_JK_OBSERVE && kind <= MNK_JK_GATHER_OBS; }
 
 // The board's own variant of API kernel `kind`, or nullptr = launch the ahead-of-time kernel: the board has a built-in
-// variant, MNK_JIT_API / MNK_JIT = 0, the kernel is not hot yet (fewer than 128 launches and 2^22 items on this board in
+// variant, MNK_JIT_API / MNK_JIT = 0, the kernel is not hot yet (fewer than 1 024 launches and 2^26 items on this board in
 // this process; MNK_JIT_API / MNK_JIT = 1: compile at the first launch), `stream` is being captured and the variant does
 // not exist yet (nothing is compiled or loaded under a capture), or the compilation failed (mnk_jit_last_error).
+#define MNK_JIT_HOT_LAUNCHES 1024u
+#define MNK_JIT_HOT_ITEMS (1ull << 26)
 hipFunction_t mnk_jit_api_function(const MnkGeom& g, int kind, int64_t items, hipStream_t stream);
 
 template <typename... P, size_t... I>

@@ -373,7 +373,10 @@ hipFunction_t mnk_jit_api_function(const MnkGeom& g, int kind, int64_t items, hi
   if (e.c.fn || e.c.failed) return e.c.fn;
   e.launches += 1;
   e.items += (uint64_t)(items > 0 ? items : 0);
-  if (jit != 1 && e.launches < 128 && e.items < (1ull << 22)) return nullptr;  // not hot yet
+  // not hot yet?  (A compilation costs 0.3-0.9 s and buys ~5 us per launch: it pays for itself after ~10^5 launches -- any
+  // training run, no smoke test.  1 024 launches into a run is early enough to lose nothing and late enough to spare
+  // short scripts the wait.)
+  if (jit != 1 && e.launches < MNK_JIT_HOT_LAUNCHES && e.items < MNK_JIT_HOT_ITEMS) return nullptr;
   if (stream) {  // nothing is compiled or loaded while the stream is being captured into a graph
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;

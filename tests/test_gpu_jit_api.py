@@ -130,14 +130,14 @@ def _play(wrap, ora, steps, rng, where):
 
 
 def test_a_kernel_switches_to_its_own_variant_once_it_is_hot(hip):
-    """Default policy (no MNK_JIT_API): the generic kernels run until a kernel has been launched 128 times on the board
-    (or has covered 2^22 items), then the board's own variant takes over -- in the middle of a game, with the same
+    """Default policy (no MNK_JIT_API): the generic kernels run until a kernel has been launched 1 024 times on the board
+    (or has covered 2^26 items), then the board's own variant takes over -- in the middle of a game, with the same
     results (the oracle checks every step on both sides of the switch)."""
     lib = hip.lib
     for key in ("MNK_JIT_API", "MNK_JIT"):
         assert os.environ.get(key) is None, "this test needs the default policy"
     lib.reload_config()
-    m, n, k, nenv = 8, 10, 4, 96  # a board no other test uses: its counters start at zero in this process
+    m, n, k, nenv = 8, 10, 4, 24  # a board no other test uses: its counters start at zero in this process
     wrap = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV), seed=3)
     sides = torch.zeros(nenv, dtype=torch.long)
     wrap.force_sides(sides)
@@ -146,18 +146,20 @@ def test_a_kernel_switches_to_its_own_variant_once_it_is_hot(hip):
     ora.sides = sides
     ora.set_opponent(LowestLegalPolicy())
     rng = np.random.default_rng(5)
-    _play(wrap, ora, 100, rng, "before the switch")  # reset = launch 1 of pre / post, then 100 steps
+    _play(wrap, ora, 1000, rng, "before the switch")  # reset = launch 1 of pre / post, then 1 000 steps
     assert not lib.jit_api_ready(m, n, k, lib.JIT_API_SP_PRE) and not lib.jit_api_ready(m, n, k, lib.JIT_API_SP_POST)
-    _play(wrap, ora, 60, rng, "across the switch")
+    _play(wrap, ora, 60, rng, "across the switch")    # (its reset + 22 steps reach launch 1 024)
     assert lib.jit_api_ready(m, n, k, lib.JIT_API_SP_PRE) and lib.jit_api_ready(m, n, k, lib.JIT_API_SP_POST)
-    # 2^22 items: one launch over 2^22 envs would do it; 8 launches over 2^19 envs do
+    # 2^26 items: 128 launches over 2^19 envs
     big = hip.Env(6, 5, 4, 1 << 19, device=DEV)
     acts = torch.zeros(1 << 19, dtype=torch.long, device=DEV)
-    for t in range(7):
-        big.step(acts + t)
+    rew = torch.empty(1 << 19, dtype=torch.float32, device=DEV)
+    done = torch.empty(1 << 19, dtype=torch.bool, device=DEV)
+    for t in range(127):
+        big.step_into(acts + t % 30, rew, done)
     assert not lib.jit_api_ready(6, 5, 4, lib.JIT_API_STEP)
-    for t in range(7, 9):
-        big.step(acts + t)
+    for t in range(2):
+        big.step_into(acts + t, rew, done)
     assert lib.jit_api_ready(6, 5, 4, lib.JIT_API_STEP)
     big.check_errors()
 
@@ -225,7 +227,7 @@ def test_nothing_is_compiled_under_a_capture_and_prepare_comes_before_it(hip, ji
 @pytest.mark.parametrize("agent,opponent,packed", [("net", "nn", False), ("net", "random", True), ("random", "random", False)])
 def test_a_captured_rollout_runs_the_boards_own_kernels(hip, agent, opponent, packed):
     """``GraphedRollout`` on a board without a built-in variant, under the DEFAULT policy (nothing forced): its warm-up
-    rollout launches every kernel a handful of times -- far from hot -- and a capture cannot compile, so the constructor
+    rollout launches every kernel a handful of times -- far from the 1 024 that make it hot -- and a capture cannot compile, so the constructor
     prepares the kernels the warm-up touched (``jit_prepare``) before it captures.  The graph then replays the
     specialised kernels, and fills the buffer like the eager loop, rollout after rollout."""
     lib = hip.lib
