@@ -357,6 +357,15 @@ class TorchVectorMnkEnv:
             mnk_hip.call("mnk_sample_legal", mnk_hip.ptr(self._planes), self.num_envs, self.m, self.n, seed, step,
                          mnk_hip.ptr(step_dev), env_id0, stream_id, mnk_hip.ptr(actions), self._stream())
 
+    def specialise_kernels(self, kinds=None) -> int:
+        """On a board without a built-in kernel variant (anything but 3x3x3, 9x9x5, 13x13x5, 15x15x5, 19x19x5) the
+        library compiles the board's own variant of an API kernel with hiprtc once that kernel is hot (1 024 launches),
+        never while a stream is being captured.  This compiles and loads NOW the variants of the kernels launched on
+        this board so far (``kinds``: an iterable of ``mnk_hip.JIT_API_*`` instead) -- call it after a warm-up run and
+        before capturing a hipGraph of your own (``selfplay.graphed`` does).  Returns how many variants are ready (0 on
+        the built-in boards)."""
+        return mnk_hip.jit_prepare(self.m, self.n, self.k, kinds)
+
     def reset_mask_(self, mask_u8) -> None:
         """Fixed-shape reset: envs with a non-zero byte in ``mask_u8`` (bool / uint8, (N,)) start over."""
         if self.num_envs:

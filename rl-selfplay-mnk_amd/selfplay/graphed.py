@@ -124,7 +124,7 @@ def _prepare_board_kernels(env) -> None:
     variant of an API kernel once that kernel is hot -- but never under a capture, so a graph captured earlier would
     replay the generic kernels for good.  The warm-up has launched exactly the kernels the capture will: compile those
     now (about a second each, once per board and process; nothing to do on 3x3x3, 9x9x5, 13x13x5, 15x15x5, 19x19x5)."""
-    mnk_hip.jit_prepare(env.m, env.n, env.k)
+    env.specialise_kernels()
 
 
 class GraphedAgentStep:

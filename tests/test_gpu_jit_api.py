@@ -179,7 +179,7 @@ def test_nothing_is_compiled_under_a_capture_and_prepare_comes_before_it(hip, ji
 
         wrap.set_opponent(RandomPolicy(c, seed=2))
         if prepare:
-            assert lib.jit_prepare(m, n, k, [lib.JIT_API_SP_STEP, lib.JIT_API_SAMPLE_LEGAL]) == 2
+            assert env.specialise_kernels([lib.JIT_API_SP_STEP, lib.JIT_API_SAMPLE_LEGAL]) == 2
         out = {"observation": torch.empty((nenv, 2, m, n), dtype=torch.float32, device=DEV),
                "action_mask": torch.empty((nenv, c), dtype=torch.bool, device=DEV),
                "rewards": torch.empty(nenv, dtype=torch.float32, device=DEV),
