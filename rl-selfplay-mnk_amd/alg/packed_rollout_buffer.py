@@ -19,9 +19,50 @@ the first ``add`` of every later rollout is handed the spill row and copies it i
 rollout) -- ``add(buffer.row(0)["packed"], ...)`` would store the zeros ``reset()`` left there.  Pass what the step (or
 ``wrapper.reset``) returned / ``wrapper.packed_obs()``, as examples/selfplay_ppo.py does.
 """
+import contextlib
+
 import torch
 
 import mnk_hip
+
+# what the PPO update reads of a rollout (get_data_loader; reference rollout_buffer.py:82-113) -- returns are
+# advantages + values, the very f32 addition the GAE kernel made (rollout_buffer.py:79) -- and everything a buffer holds
+UPDATE_FIELDS = ("planes", "actions", "log_probs", "values", "advantages")
+ALL_FIELDS = UPDATE_FIELDS + ("returns", "rewards", "dones")
+
+
+def all_gather_fields(fields, exchange=None, group=None, stream=None, out=None):
+    """The exchange step of a sharded rollout buffer on plain tensors: every ``fields[name]`` (``[T, ...]``, contiguous,
+    the same shape on every rank) is all-gathered rank-major into ``out[name]`` (``[world * T, ...]``: rank r's steps at
+    ``[r * T, (r + 1) * T)``; allocated when ``out`` is None).  ``exchange``: a ``selfplay.exchange.RecordExchange`` --
+    the collectives are then ``mnk_allgather_records`` of the C ABI (RCCL over xGMI) on ``stream``; without it the
+    ``torch.distributed`` ``group`` carries them (``gloo`` in the CPU tests).  One collective per field, in the order of
+    ``fields`` on every rank."""
+    if exchange is not None:
+        world = exchange.world
+    else:
+        import torch.distributed as dist
+
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    out = {} if out is None else out
+    for name, send in fields.items():
+        if not send.is_contiguous():
+            raise ValueError(f"field {name!r} must be contiguous")
+        recv = out.get(name)
+        if recv is None:
+            recv = out[name] = torch.empty((world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        if recv.shape[0] != world * send.shape[0] or recv.shape[1:] != send.shape[1:] or recv.dtype != send.dtype or not recv.is_contiguous():
+            raise ValueError(f"out[{name!r}] must be a contiguous {send.dtype} tensor of {world} x {tuple(send.shape)}")
+        a, b = send.reshape(-1), recv.reshape(-1)
+        if a.dtype == torch.bool:  # (byte for byte; not every backend takes bool)
+            a, b = a.view(torch.uint8), b.view(torch.uint8)
+        if exchange is not None:
+            exchange.all_gather(a, b, stream)
+        elif world > 1:
+            dist.all_gather_into_tensor(b, a, group=group)
+        else:
+            b.copy_(a)
+    return out
 
 
 class PackedRolloutBuffer:
@@ -134,6 +175,41 @@ class PackedRolloutBuffer:
                          mnk_hip.ptr(idx), b, mnk_hip.ptr(obs), mnk_hip.obs_code(obs), mnk_hip.ptr(mask), 1,
                          mnk_hip.ptr(self._err), mnk_hip.stream_ptr(dev))
         return obs, mask
+
+    def all_gather(self, exchange=None, group=None, stream=None, out=None, fields=UPDATE_FIELDS):
+        """The exchange step of a SHARDED self-play rollout (the RCCL all-gather of rollout buffers,
+        with the log-probabilities and values a network policy adds): every rank has filled its buffer from its own
+        block of envs (``wrapper.env_id0 = rank * num_envs``, the samplers alike) and computed its advantages; this
+        returns a buffer of ``world * n_steps`` steps of ``num_envs`` envs holding everybody's -- rank r's rollout in steps
+        ``[r * n_steps, (r + 1) * n_steps)``, i.e. flat sample id ``(r * n_steps + t) * num_envs + i`` -- whose
+        ``get_data_loader`` draws minibatches over all ``world * n_steps * num_envs`` samples.  On the wire: the packed
+        planes and 20 B of scalars per agent-step (52 B at 9x9; the reference's layout is 750 B) with ``fields`` =
+        ``UPDATE_FIELDS`` (what the PPO update reads; ``returns`` are recomputed as ``advantages + values``, bit for bit
+        what the GAE kernel stored), everything with ``ALL_FIELDS``.  ``exchange`` / ``group`` / ``stream``: see
+        ``all_gather_fields``; ``out``: the buffer a previous call returned (reused)."""
+        if self.ptr != self.n_steps:
+            raise RuntimeError(f"all_gather of a buffer that holds {self.ptr} of {self.n_steps} steps")
+        unknown = [f for f in fields if f not in ALL_FIELDS]
+        if unknown:
+            raise ValueError(f"unknown fields {unknown}")
+        if exchange is not None:
+            world = exchange.world
+        else:
+            import torch.distributed as dist
+
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if out is None:
+            out = PackedRolloutBuffer(world * self.n_steps, self.num_envs, self.m, self.n, device=self.device, keep_storage=True)
+        if (out.n_steps, out.num_envs, out.m, out.n) != (world * self.n_steps, self.num_envs, self.m, self.n):
+            raise ValueError("out was made for another world size / buffer shape")
+        all_gather_fields({f: getattr(self, f) for f in fields}, exchange, group, stream,
+                          out={f: getattr(out, f) for f in fields})
+        if "returns" not in fields and "advantages" in fields and "values" in fields:
+            ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+            with ctx:  # (after the collectives, on their stream)
+                torch.add(out.advantages, out.values, out=out.returns)  # rollout_buffer.py:79
+        out.ptr = out.n_steps
+        return out
 
     def get_data_loader(self, batch_size, normalize_advantages=True):
         """reference rollout_buffer.py:82-113: (obs, actions, log_probs, returns, advantages, masks, values)"""

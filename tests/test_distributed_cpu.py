@@ -103,6 +103,51 @@ def test_sharded_rollout_gathers_to_the_single_process_result(tmp_path, m, n, k,
         assert np.array_equal(got["stats"], stats)
 
 
+def _fields_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    entry._ensure_path()
+    from alg.packed_rollout_buffer import all_gather_fields
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        t, n = 5, 7
+        g = torch.Generator().manual_seed(100 + rank)
+        fields = {"planes": torch.randint(-2 ** 40, 2 ** 40, (t, 2, 2, n), generator=g),
+                  "actions": torch.randint(0, 81, (t, n), generator=g),
+                  "log_probs": torch.randn(t, n, generator=g),
+                  "dones": torch.rand(t, n, generator=g) < 0.3}
+        out = all_gather_fields(fields)
+        again = all_gather_fields(fields, out=out)          # the buffers of a previous call are reused
+        assert all(again[k] is out[k] for k in fields)
+        try:
+            all_gather_fields({"planes": fields["planes"]}, out={"planes": torch.empty((t, 2, 2, n), dtype=torch.int64)})
+            raise SystemExit("a receive buffer for one rank was accepted")
+        except ValueError:
+            pass
+        try:
+            all_gather_fields({"x": fields["planes"].transpose(0, 3)})
+            raise SystemExit("a non-contiguous field was accepted")
+        except ValueError:
+            pass
+        torch.save({"mine": fields, "all": out}, os.path.join(out_dir, f"fields{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_buffer_fields_all_gather_rank_major(tmp_path):
+    """``alg.packed_rollout_buffer.all_gather_fields`` -- the exchange step of a sharded self-play rollout buffer
+    (``PackedRolloutBuffer.all_gather``: SURVEY 8e's all-gather of rollout buffers with the log-probabilities and values
+    a network policy adds) on plain tensors, world size 2 over gloo: every rank ends up with every rank's steps, rank r's
+    at ``[r * T, (r + 1) * T)``, int64 / f32 / bool alike."""
+    world = 2
+    mp.spawn(_fields_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(tmp_path / f"fields{r}.pt") for r in range(world)]
+    for name in ("planes", "actions", "log_probs", "dones"):
+        want = torch.cat([got[r]["mine"][name] for r in range(world)], dim=0)
+        for r in range(world):
+            assert got[r]["all"][name].dtype == want.dtype and torch.equal(got[r]["all"][name], want), (name, r)
+
+
 def test_action_log_formats_round_trip_between_the_oracle_and_the_host_code():
     """Every log format: the oracle's numpy packing of random actions, read back by the product's torch unpacker
     (``selfplay.random_rollout.unpack_action_log``), gives the actions; word counts agree with the library's."""

@@ -93,6 +93,25 @@ with torch.cuda.stream(side):
     logs3 = gather_action_logs(rec, exchange=ex, stream=side)
 torch.cuda.current_stream().wait_stream(side)
 assert torch.equal(logs3.msg[0], rec.msg)
+# the exchange step of the self-play wrapper's rollout buffer through the same communicator, on the side stream, in both
+# forms (PackedRolloutBuffer.all_gather: planes + actions + log-probabilities + values + advantages; a bool field too)
+from alg.packed_rollout_buffer import ALL_FIELDS, PackedRolloutBuffer
+buf = PackedRolloutBuffer(6, 300, 9, 9, device="cuda:0")
+gen = torch.Generator(device=dev).manual_seed(2)
+buf.planes.random_(generator=gen); buf.actions.random_(0, 81, generator=gen)
+for f in (buf.log_probs, buf.values, buf.advantages, buf.rewards):
+    f.normal_(generator=gen)
+buf.returns.copy_(buf.advantages + buf.values); buf.dones.copy_(torch.rand(6, 300, device=dev, generator=gen) < 0.2)
+buf.ptr = 6
+for direct in (False, True):
+    ex.direct = direct
+    done.record()
+    with torch.cuda.stream(side):
+        side.wait_event(done)
+        got_buf = buf.all_gather(exchange=ex, stream=side, fields=ALL_FIELDS if direct else ("planes", "actions", "log_probs", "values", "advantages"))
+    torch.cuda.current_stream().wait_stream(side)
+    for f in ("planes", "actions", "log_probs", "values", "advantages", "returns") + (("rewards", "dones") if direct else ()):
+        assert torch.equal(getattr(got_buf, f), getattr(buf, f)), (direct, f)
 odd = torch.arange(1, 1 + 13, dtype=torch.uint8, device=dev)   # a message that is not a multiple of 8 bytes
 got = torch.zeros(13, dtype=torch.uint8, device=dev)
 ex.all_gather(odd, got)
@@ -180,6 +199,126 @@ def test_two_ranks_exchange_keyframed_logs_and_rebuild_each_others_records(m, n,
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2",
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, "-c", _TWO_RANK_CHILD % {"root": ROOT, "m": m, "n": n, "k": k}], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for rank, (out, err) in enumerate(outs):
+        assert f"RANK_OK {rank}" in out, out[-2000:] + err[-4000:]
+
+
+_TWO_RANK_BUFFER_CHILD = r"""
+import copy, os, sys
+sys.path[:0] = [%(root)r, os.path.join(%(root)r, "rl-selfplay-mnk_amd")]
+import torch, torch.distributed as dist
+from alg.packed_rollout_buffer import ALL_FIELDS, UPDATE_FIELDS, PackedRolloutBuffer
+from env.torch_vector_mnk_env import TorchVectorMnkEnv
+from selfplay.policy import FusedNNPolicy, HipSampler
+from selfplay.torch_self_play_wrapper import TorchSelfPlayWrapper
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+m, n, k, nenv, steps = 9, 9, 5, 160, 12
+c = m * n
+
+
+class RowNet(torch.nn.Module):
+    # a "network" made of element-wise operations and exact small-integer sums only: the logits of a row are the same
+    # bits whatever the batch size (a conv / GEMM may pick another algorithm for 160 rows than for 320)
+    def __init__(self, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.w = torch.nn.Parameter(torch.randn(2, c, generator=g))
+        self.b = torch.nn.Parameter(torch.randn(c, generator=g))
+
+    def forward(self, obs, action_mask=None):
+        x = obs.float().flatten(2)                                  # [B, 2, C] of 0 / 1
+        lead = (x[:, 0].sum(1, keepdim=True) - x[:, 1].sum(1, keepdim=True))  # exact
+        logits = x[:, 0] * self.w[0] + x[:, 1] * self.w[1] + self.b + 0.25 * lead
+
+        class Dist:
+            pass
+
+        d = Dist()
+        d.logits = logits
+        return d, torch.tanh(0.125 * lead)
+
+
+agent, opp_net = RowNet(1).to(dev).eval(), RowNet(2).to(dev).eval()
+
+
+def rollout(count, id0):
+    # the shard's global env ids key every random stream: the wrapper's sides, the agent's and the opponent's draws
+    wrap = TorchSelfPlayWrapper(TorchVectorMnkEnv(m, n, k, count, device="cuda:0"), seed=11)
+    wrap.env_id0 = id0
+    opp = FusedNNPolicy(copy.deepcopy(opp_net), seed=5)
+    opp._sampler.env_id0 = id0
+    wrap.set_opponent(opp)
+    sampler = HipSampler(seed=7)
+    sampler.env_id0 = id0
+    buf = PackedRolloutBuffer(steps, count, m, n, device="cuda:0")
+    wrap.attach_sink(buf)
+    obs, _ = wrap.reset()
+    for t in range(steps):
+        with torch.no_grad():
+            d, values = agent(obs["observation"], None)
+        cur = buf.row(t)["packed"]                                   # where reset() / the previous step put the planes
+        nxt, rew, term, trunc, info = wrap.step_logits(d.logits, obs["action_mask"], sampler)
+        buf.add(cur, info["actions"], rew, values, info["log_probs"], term | trunc)
+        obs = nxt
+    with torch.no_grad():
+        _, last = agent(obs["observation"], None)
+    buf.compute_advantages_and_returns(last.reshape(-1), 0.99, 0.95)
+    wrap.env.check_errors()
+    return buf
+
+
+mine = rollout(nenv, rank * nenv)
+full = mine.all_gather()                                             # the exchange step (gloo here, RCCL on the GPUs of a node)
+everything = mine.all_gather(fields=ALL_FIELDS)
+assert full.n_steps == world * steps and full.ptr == full.n_steps and full.num_envs == nenv
+for f in ("planes", "actions", "log_probs", "values", "advantages", "returns"):   # returns: recomputed == gathered
+    assert torch.equal(getattr(full, f), getattr(everything, f)), f
+    assert torch.equal(getattr(full, f)[rank * steps:(rank + 1) * steps], getattr(mine, f)), f
+assert not full.rewards.any() and torch.equal(everything.dones[rank * steps:(rank + 1) * steps], mine.dones)
+again = mine.all_gather(out=full)
+assert again is full
+if rank == 0:   # the shards together are what one process with all the envs plays and stores
+    whole = rollout(world * nenv, 0)
+    for r in range(world):
+        rows, cols = slice(r * steps, (r + 1) * steps), slice(r * nenv, (r + 1) * nenv)
+        assert torch.equal(everything.planes[rows], whole.planes[..., cols]), r
+        for f in ("actions", "log_probs", "values", "advantages", "returns", "rewards", "dones"):
+            assert torch.equal(getattr(everything, f)[rows], getattr(whole, f)[:, cols]), (r, f)
+    # a minibatch drawn from the gathered buffer = the same samples of the single-process buffer
+    g = torch.Generator().manual_seed(4)
+    pick = torch.randperm(world * steps * nenv, generator=g)[:700].to(dev)
+    r_, t_, i_ = pick // (steps * nenv), (pick // nenv) %% steps, pick %% nenv
+    obs_a, mask_a = full.gather(pick)
+    obs_b, mask_b = whole.gather(t_ * (world * nenv) + r_ * nenv + i_)
+    assert torch.equal(obs_a, obs_b) and torch.equal(mask_a, mask_b)
+    batches = list(full.get_data_loader(4096))
+    assert sum(b[0].shape[0] for b in batches) == world * steps * nenv
+dist.barrier()
+dist.destroy_process_group()
+print("RANK_OK", rank)
+"""
+
+
+def test_two_ranks_all_gather_their_self_play_rollout_buffers():
+    """SURVEY 8e for the self-play wrapper's path: two rank processes (gloo; both on this box's GPU), each playing a
+    rollout of network agent against network opponent on its own block of envs (global env ids key the sides and both
+    samplers) straight into a ``PackedRolloutBuffer`` (the sink), GAE per shard, then ``buffer.all_gather()`` -- the
+    packed planes + actions + log-probabilities + values + advantages of every rank, 52 B per agent-step at 9x9.  The
+    gathered buffer holds every shard's steps, its recomputed returns are the gathered ones bit for bit, and the two
+    shards together are what a single process with all the envs plays, stores and draws minibatches from."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _TWO_RANK_BUFFER_CHILD % {"root": ROOT}], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
     for rank, (out, err) in enumerate(outs):
