@@ -115,6 +115,46 @@ def test_a_launch_that_would_not_fit_the_lds_stays_on_two_launches(hip, jit_api)
         assert not lib.jit_api_ready(31, 31, 6, lib.jit_api_draw_kind(0, dtype))
 
 
+def test_reference_fixtures_through_the_specialised_kernels(hip, jit_api, golden_dir):
+    """What the REFERENCE recorded on boards without a built-in variant (tests/golden, made by the imported reference:
+    env op-logs of 4x6x3 and 7x9x7, the 4x6x3 wrapper trace, the edge scenarios on such boards), replayed on the
+    board's own run-time compiled kernels: the fixtures pin the oracle, this pins the specialised kernels to the same
+    data directly."""
+    lib = jit_api
+    from replay import golden_files, play_scenario, replay_env_log, replay_selfplay_trace
+    from scenarios import SCENARIOS
+
+    boards = set()
+    for path in golden_files(golden_dir, "env_"):
+        log = np.load(path)
+        m, n, k, nenv, _ = (int(v) for v in log["geom"])
+        if (m, n, k) in ((4, 6, 3), (7, 9, 7)):
+            replay_env_log(hip.Env(m, n, k, nenv, device=DEV), log)
+            replay_env_log(hip.Env(m, n, k, nenv, device=DEV, obs_dtype=torch.uint8), log)
+            boards.add((m, n, k))
+    assert boards == {(4, 6, 3), (7, 9, 7)}
+    for (m, n, k) in boards:
+        assert lib.jit_api_ready(m, n, k, lib.JIT_API_STEP) and lib.jit_api_ready(m, n, k, lib.JIT_API_STEP_SUBSET)
+    traces = [p for p in golden_files(golden_dir, "selfplay_") if "4x6x3" in p]
+    assert traces
+    for path in traces:
+        log = np.load(path)
+        m, n, k, nenv, _ = (int(v) for v in log["geom"])
+        wrap = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV))
+        wrap.set_opponent(sp.OPP[path.split("_")[-2]]())
+        replay_selfplay_trace(wrap, log, lambda w, sides: w.force_sides(torch.from_numpy(sides.astype(np.int64))))
+    assert lib.jit_api_ready(4, 6, 3, lib.JIT_API_SP_PRE) and lib.jit_api_ready(4, 6, 3, lib.JIT_API_SP_POST)
+    edges = np.load(f"{golden_dir}/edges.npz")
+    played = 0
+    for name, sc in sorted(SCENARIOS.items()):
+        if (sc["m"], sc["n"], sc["k"]) in ((3, 3, 3), (9, 9, 5), (13, 13, 5), (15, 15, 5), (19, 19, 5)):
+            continue
+        got = play_scenario(hip.Env(sc["m"], sc["n"], sc["k"], 1, device=DEV), sc)
+        assert np.array_equal(got, edges[name]), name
+        played += 1
+    assert played >= 3
+
+
 def _play(wrap, ora, steps, rng, where):
     """`steps` agent-steps of random legal moves on the HIP wrapper and on the oracle, compared after every step"""
     o1, _ = wrap.reset()
