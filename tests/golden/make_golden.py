@@ -54,6 +54,15 @@ SELFPLAY_CASES = [
 
 OPPONENTS = {"lowest": LowestLegalPolicy, "highest": HighestLegalPolicy, "hash": MaskHashPolicy}
 
+# Round 4 (``--more-boards``): boards WITHOUT a built-in kernel variant -- their kernels are compiled at run time
+# (csrc/mnk_jit.hip) -- under a prefix of their own, so the indices the older tests address the files above by stay put:
+#   boards_env_<m>x<n>x<k>_s<seed>.npz, boards_selfplay_<m>x<n>x<k>_<opp>_s<seed>.npz
+# 1 / 2 / 5 register words per plane, a connect-four-shaped board, rows wider than 31 cells (table write-out)
+MORE_ENV_CASES = [(5, 5, 4, 48, 60, (0,)), (6, 7, 4, 64, 90, (0,)), (12, 12, 5, 48, 260, (0,)), (10, 10, 5, 40, 200, (0,)),
+                  (3, 33, 3, 24, 120, (0,))]
+MORE_SELFPLAY_CASES = [(6, 7, 4, 64, 90, "hash", 0), (12, 12, 5, 40, 220, "highest", 0), (5, 5, 4, 48, 60, "lowest", 0),
+                       (10, 10, 5, 32, 180, "hash", 1)]
+
 
 def _state(env, m, n):
     return (
@@ -212,7 +221,22 @@ def make_masked_logits():
     return out
 
 
+def more_boards():
+    RefEnv, RefWrap, _ = import_reference()
+    for (m, n, k, nenv, steps, seeds) in MORE_ENV_CASES:
+        for seed in seeds:
+            path = os.path.join(OUT, f"boards_env_{m}x{n}x{k}_s{seed}.npz")
+            np.savez_compressed(path, **make_env_log(RefEnv, m, n, k, nenv, steps, seed))
+            print("wrote", os.path.basename(path), os.path.getsize(path))
+    for (m, n, k, nenv, steps, opp, seed) in MORE_SELFPLAY_CASES:
+        path = os.path.join(OUT, f"boards_selfplay_{m}x{n}x{k}_{opp}_s{seed}.npz")
+        np.savez_compressed(path, **make_selfplay_trace(RefEnv, RefWrap, m, n, k, nenv, steps, opp, seed))
+        print("wrote", os.path.basename(path), os.path.getsize(path))
+
+
 def main():
+    if "--more-boards" in sys.argv:  # only the round-4 additions: the older files are left as they are
+        return more_boards()
     RefEnv, RefWrap, _ = import_reference()
     for (m, n, k, nenv, steps, seeds) in ENV_CASES:
         for seed in seeds:

@@ -155,6 +155,42 @@ def test_reference_fixtures_through_the_specialised_kernels(hip, jit_api, golden
     assert played >= 3
 
 
+@pytest.mark.parametrize("mode", ["generic", "specialised"])
+def test_reference_fixtures_of_more_boards(hip, mode, golden_dir):
+    """Round 4's fixtures (``tests/golden/make_golden.py --more-boards``: the imported reference's env op-logs on 5x5x4,
+    6x7x4, 10x10x5, 12x12x5, 3x33x3 and wrapper traces on 6x7x4, 12x12x5, 5x5x4, 10x10x5 -- boards whose HIP kernels are
+    compiled at run time) replayed on the generic kernels (MNK_JIT_API=0) and on the boards' own (MNK_JIT_API=1), with
+    f32 and narrow observations: what the reference recorded, bit for bit, either way."""
+    lib = hip.lib
+    from replay import golden_files, replay_env_log, replay_selfplay_trace
+
+    saved = os.environ.get("MNK_JIT_API")
+    os.environ["MNK_JIT_API"] = "1" if mode == "specialised" else "0"
+    lib.reload_config()
+    try:
+        envs, traces = golden_files(golden_dir, "boards_env_"), golden_files(golden_dir, "boards_selfplay_")
+        assert len(envs) == 5 and len(traces) == 4
+        for path in envs:
+            log = np.load(path)
+            m, n, k, nenv, _ = (int(v) for v in log["geom"])
+            replay_env_log(hip.Env(m, n, k, nenv, device=DEV), log)
+            replay_env_log(hip.Env(m, n, k, nenv, device=DEV, obs_dtype=torch.bfloat16), log)
+            assert mode == "generic" or lib.jit_api_ready(m, n, k, lib.JIT_API_STEP), (m, n, k)
+        for j, path in enumerate(traces):
+            log = np.load(path)
+            m, n, k, nenv, _ = (int(v) for v in log["geom"])
+            wrap = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV, obs_dtype=[torch.float32, torch.uint8][j % 2]))
+            wrap.set_opponent(sp.OPP[path.split("_")[-2]]())
+            replay_selfplay_trace(wrap, log, lambda w, sides: w.force_sides(torch.from_numpy(sides.astype(np.int64))))
+            assert mode == "generic" or lib.jit_api_ready(m, n, k, lib.JIT_API_SP_POST), (m, n, k)
+    finally:
+        if saved is None:
+            os.environ.pop("MNK_JIT_API", None)
+        else:
+            os.environ["MNK_JIT_API"] = saved
+        lib.reload_config()
+
+
 def _play(wrap, ora, steps, rng, where):
     """`steps` agent-steps of random legal moves on the HIP wrapper and on the oracle, compared after every step"""
     o1, _ = wrap.reset()

@@ -57,6 +57,25 @@ def test_oracle_selfplay_trace(golden_dir, idx):
     replay_selfplay_trace(wrap, log, _oracle_set_sides)
 
 
+def test_oracle_on_the_fixtures_of_more_boards(golden_dir):
+    """Round 4: env op-logs and wrapper traces recorded from the reference on boards WITHOUT a built-in kernel variant
+    (1 / 2 / 4 / 5 register words per plane, a connect-four shape, rows of 33 cells; ``make_golden.py --more-boards``):
+    the oracle replays them like the older ones, so they pin it on the boards whose HIP kernels are compiled at run
+    time (tests/test_gpu_jit_api.py replays the same files on those)."""
+    envs, traces = golden_files(golden_dir, "boards_env_"), golden_files(golden_dir, "boards_selfplay_")
+    assert len(envs) == 5 and len(traces) == 4
+    for path in envs:
+        log = np.load(path)
+        m, n, k, nenv, _ = (int(v) for v in log["geom"])
+        replay_env_log(OracleVectorEnv(m, n, k, nenv), log)
+    for path in traces:
+        log = np.load(path)
+        m, n, k, nenv, _ = (int(v) for v in log["geom"])
+        wrap = _ReplayOracleSelfPlay(OracleVectorEnv(m, n, k, nenv))
+        wrap.set_opponent(OPP[path.split("_")[-2]]())
+        replay_selfplay_trace(wrap, log, _oracle_set_sides)
+
+
 @pytest.mark.parametrize("name", sorted(SCENARIOS))
 def test_oracle_edge_scenarios(golden_dir, name):
     sc = SCENARIOS[name]
