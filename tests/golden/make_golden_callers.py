@@ -223,7 +223,20 @@ def make_ppo_learn_with_last_values(*case):
     return out
 
 
+# Round 4 (``--more-boards``): a learn() recording on a board WITHOUT a built-in kernel variant, under a prefix of its own
+# (the older tests address ppo_learn_* by index): boards_ppo_learn_6x7x4_n64_t16.npz
+MORE_PPO_CASES = [(6, 7, 4, 64, 16, "cnn_b_s", "hash1", 2)]
+
+
 def main():
+    if "--more-boards" in sys.argv:
+        torch.set_num_threads(1)
+        for case in MORE_PPO_CASES:
+            m, n, k, nenv, n_steps, arch, opp, seed = case
+            path = os.path.join(OUT, f"boards_ppo_learn_{m}x{n}x{k}_n{nenv}_t{n_steps}.npz")
+            np.savez_compressed(path, **make_ppo_learn_with_last_values(*case))
+            print("wrote", os.path.basename(path), os.path.getsize(path))
+        return
     # one intra-op thread: the PPO update between the two learn() calls reduces gradients over the batch, and the
     # sampled actions of the second call depend on the last bits of those sums -- with one thread the fixture
     # regenerates byte for byte on any machine

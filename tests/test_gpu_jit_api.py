@@ -191,6 +191,50 @@ def test_reference_fixtures_of_more_boards(hip, mode, golden_dir):
         lib.reload_config()
 
 
+@pytest.mark.parametrize("mode", ["generic", "specialised"])
+def test_reference_learn_rollouts_on_a_board_without_a_built_in_variant(hip, mode, golden_dir):
+    """Two consecutive ``PPOAgent.learn`` rollouts of the reference on 6x7x4 (``boards_ppo_learn_6x7x4_n64_t16.npz``:
+    its own ``cnn_b_s``, sampling, ``RolloutBuffer``, GAE and one PPO update in between, recorded through a proxy),
+    replayed on the HIP wrapper with the drop-in buffer attached as the sink -- on the generic kernels and on the
+    board's own run-time compiled ones: every buffer field and the episode statistics equal the reference's."""
+    lib = hip.lib
+    from alg.rollout_buffer import RolloutBuffer
+    from oracle.policies import MaskHashPolicy
+    from replay import golden_files, replay_ppo_learn
+
+    saved = os.environ.get("MNK_JIT_API")
+    os.environ["MNK_JIT_API"] = "1" if mode == "specialised" else "0"
+    lib.reload_config()
+    try:
+        (path,) = golden_files(golden_dir, "boards_ppo_learn_")
+        log = np.load(path)
+        m, n, k, nenv, n_steps = (int(v) for v in log["geom"])
+        wrap = hip.Wrapper(hip.Env(m, n, k, nenv, device=DEV))
+        wrap.set_opponent(MaskHashPolicy(1))
+        wrap.track_episodes()
+        buf = RolloutBuffer(n_steps, nenv, (2, m, n), m * n, device=DEV)
+        wrap.attach_sink(buf)
+        calls = []
+
+        def make_buffer(*_):
+            if calls:
+                buf.reset()  # the end of the previous learn(): ppo.py:146
+            calls.append(1)
+            return buf
+
+        replay_ppo_learn(wrap, make_buffer, log,
+                         lambda w, sides: w.force_sides(torch.from_numpy(sides.astype(np.int64))),
+                         episode_stats=wrap.pop_episode_stats)
+        assert len(calls) == 2
+        assert mode == "generic" or (lib.jit_api_ready(m, n, k, lib.JIT_API_SP_PRE) and lib.jit_api_ready(m, n, k, lib.JIT_API_SP_POST))
+    finally:
+        if saved is None:
+            os.environ.pop("MNK_JIT_API", None)
+        else:
+            os.environ["MNK_JIT_API"] = saved
+        lib.reload_config()
+
+
 def _play(wrap, ora, steps, rng, where):
     """`steps` agent-steps of random legal moves on the HIP wrapper and on the oracle, compared after every step"""
     o1, _ = wrap.reset()

@@ -87,3 +87,16 @@ def test_oracle_ppo_learn_rollout(golden_dir, idx):
     wrap.set_opponent(MaskHashPolicy(0 if m == 3 else 1))
     assert log["call0/dones"].any() and log["call1/dones"].any()  # games end inside both learn calls
     replay_ppo_learn(wrap, OracleRolloutBuffer, log, _oracle_set_sides)
+
+
+def test_oracle_ppo_learn_rollout_on_a_board_without_a_built_in_variant(golden_dir):
+    """Round 4: the same recording on 6x7x4 (``make_golden_callers.py --more-boards``) -- a board whose HIP kernels are
+    compiled at run time; tests/test_gpu_jit_api.py replays it on those, through the sink"""
+    (path,) = golden_files(golden_dir, "boards_ppo_learn_")
+    log = np.load(path)
+    m, n, k, nenv, _ = (int(v) for v in log["geom"])
+    assert (m, n, k) == (6, 7, 4)
+    wrap = _ReplayOracleSelfPlay(OracleVectorEnv(m, n, k, nenv))
+    wrap.set_opponent(MaskHashPolicy(1))
+    assert log["call0/dones"].any() and log["call1/dones"].any()
+    replay_ppo_learn(wrap, OracleRolloutBuffer, log, _oracle_set_sides)
