@@ -314,6 +314,7 @@ def api_path_graphed_rate(env, seed, plies_per_graph=64, replays=8, fused_reset=
     with torch.cuda.stream(side):
         body()
     torch.cuda.current_stream(dev).wait_stream(side)
+    env.specialise_kernels()  # a board without a built-in variant: its own kernels go into the graph (nothing compiles under a capture)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         body()
@@ -350,6 +351,7 @@ def api_path_one_launch_rate(env, seed, plies_per_graph=64, replays=8):
         with torch.cuda.stream(side):
             body()
         torch.cuda.current_stream(dev).wait_stream(side)
+        e.specialise_kernels()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             body()
