@@ -1095,3 +1095,41 @@ def test_checkpoint_resume_is_bit_exact(hip, tmp_path):
     assert torch.equal(got.planes, want.planes) and torch.equal(got.meta, want.meta) and torch.equal(a.stats, b.stats)
     with pytest.raises(ValueError, match="state is for"):
         hip.Env(3, 3, 3, nenv, device=DEV).load_state_dict(state["env"])
+
+
+def test_observations_beyond_4_GiB_are_addressed_with_64_bits(hip):
+    """Sized for the device (288 GB): 2^23 envs of 9x9x5 -- an f32 observation of 5.4 GB, past any 32-bit byte offset.
+    The last 4 096 envs of the big batch play, see and are rewarded exactly like a 4 096-env wrapper keyed with their
+    global env ids (``env_id0``), and so do the first 4 096: the one-launch self-play step, then ``observe``."""
+    m, n, k, nenv, part = 9, 9, 5, 1 << 23, 4096
+    c = m * n
+
+    def make(count, id0):
+        w = hip.Wrapper(hip.Env(m, n, k, count, device=DEV), seed=31)
+        w.env_id0 = id0
+        w.set_opponent(hip.policy.RandomPolicy(c, seed=9))
+        out = {"observation": torch.empty((count, 2, m, n), dtype=torch.float32, device=DEV),
+               "action_mask": torch.empty((count, c), dtype=torch.bool, device=DEV),
+               "rewards": torch.empty(count, dtype=torch.float32, device=DEV),
+               "terminated": torch.empty(count, dtype=torch.bool, device=DEV)}
+        return w, out
+
+    big, big_out = make(nenv, 0)
+    assert big_out["observation"].numel() * 4 > (1 << 32)
+    parts = [(make(part, 0), slice(0, part)), (make(part, nenv - part), slice(nenv - part, nenv))]
+    big.reset(out=big_out)
+    for (w, out), rows in parts:
+        w.reset(out=out)
+        assert torch.equal(out["observation"], big_out["observation"][rows]) and torch.equal(out["action_mask"], big_out["action_mask"][rows])
+    acts = torch.empty(nenv, dtype=torch.long, device=DEV)
+    for t in range(8):
+        big.env.sample_legal_into(acts, seed=77, step=t)    # a legal move per env, keyed by global env id
+        big.step(acts, out=big_out)
+        for (w, out), rows in parts:
+            w.step(acts[rows].clone(), out=out)
+            for key in out:
+                assert torch.equal(out[key], big_out[key][rows]), (t, key, rows)
+            assert torch.equal(w.agent_side, big.agent_side[rows]) and torch.equal(w.env._planes, big.env._planes[..., rows])
+    got = big.get_agent_obs()  # (k_observe: another 5.4 GB)
+    assert torch.equal(got["observation"], big_out["observation"]) and torch.equal(got["action_mask"], big_out["action_mask"])
+    big.env.check_errors()
