@@ -58,10 +58,12 @@ def all_gather_fields(fields, exchange=None, group=None, stream=None, out=None):
             a, b = a.view(torch.uint8), b.view(torch.uint8)
         if exchange is not None:
             exchange.all_gather(a, b, stream)
-        elif world > 1:
-            dist.all_gather_into_tensor(b, a, group=group)
-        else:
-            b.copy_(a)
+            continue
+        with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+            if world > 1:
+                dist.all_gather_into_tensor(b, a, group=group)
+            else:
+                b.copy_(a)
     return out
 
 
