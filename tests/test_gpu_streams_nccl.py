@@ -325,6 +325,34 @@ def test_two_ranks_all_gather_their_self_play_rollout_buffers():
         assert f"RANK_OK {rank}" in out, out[-2000:] + err[-4000:]
 
 
+def test_sharded_self_play_ppo_example_keeps_its_replicas_identical():
+    """examples/selfplay_ppo_sharded.py: two ranks (gloo; both on this box's GPU) play their own env shards, all-gather
+    their rollout buffers and run the same PPO update on the union -- no gradient communication -- and their weights stay
+    bit-identical while the policy learns; then one rank on the RCCL backend, the all-gather through the C ABI's
+    communicator."""
+    import re
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for var in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(var, None)
+    script = os.path.join(ROOT, "examples", "selfplay_ppo_sharded.py")
+    out = subprocess.run([sys.executable, script, "--ranks", "2", "--backend", "gloo", "--envs", "512", "--iters", "20"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("iter")]
+    assert len(lines) == 2 and all("replicas identical: True" in ln for ln in lines), out.stdout[-2000:]
+    assert "2 ranks x 512 envs, 16384 samples per update (32 gathered steps)" in lines[-1]
+    assert float(re.search(r"score vs random ([0-9.]+)", lines[-1]).group(1)) > 0.6, lines[-1]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, script, "--backend", "nccl", "--envs", "512", "--iters", "3"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "1 ranks x 512 envs" in out.stdout and "replicas identical: True" in out.stdout, out.stdout[-2000:]
+
+
 @pytest.mark.parametrize("extra", [[], ["--allgather", "direct", "--keyframe", "1"], ["--gather", "records"], ["FORCE_SWITCH"],
                                    ["--exchange-every", "2"], ["--exchange-every", "2", "--gather", "records"]])
 def test_bench_multi_gpu_code_path_rehearsed_on_one_gpu(extra):
