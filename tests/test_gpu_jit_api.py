@@ -80,6 +80,8 @@ def test_folded_draw_of_any_row_width(hip, jit_api, m, n, k, nenv, opponent):
     for the same uniform): == ``sampler.draw`` + ``wrapper.step``, f32 / bf16 / absent logits, stochastic and
     deterministic, every output and the whole state"""
     lib = jit_api
+    if nenv == 65536 and opponent == "net":
+        pytest.skip("the full-size batch runs with the random and the scripted opponent (a conv net at this batch is 20 s of MIOpen)")
     from alg.rollout_buffer import RolloutBuffer
     from selfplay import graphed, policy
 
