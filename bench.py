@@ -1339,6 +1339,9 @@ def main():
             out["rollout_stats"] = {"episodes": stats[0], "mean_plies": stats[4] / max(stats[0], 1),
                                     "draw_rate": stats[3] / max(stats[0], 1)}
         out["gpu"] = gpu_identity(dev)
+        jit = mnk_hip.jit_stats()
+        if jit["compiled"] or jit["cache_hits"] or jit["failed"]:  # a board without a built-in variant: what hiprtc did for it
+            out["jit"] = jit
         if not multi and not args.no_api_path:
             out["roofline"]["measured_write_ceiling_GBps"] = write_ceiling_GBps(dev, nenv, chunk, rows)
             out["roofline"]["frac_of_measured_write_ceiling"] = achieved / out["roofline"]["measured_write_ceiling_GBps"]
